@@ -1,0 +1,266 @@
+/*
+ * krepp_amd.h — C-ABI of the MI355X-native `krepp dist` query path.
+ *
+ * The reference (bo1929/krepp v0.8.3) has no FFI/plugin layer; its drop-in
+ * surfaces are the CLI, the on-disk index, and one internal seam:
+ *
+ *     IBatch(index, qs, hdist_th, chisq, dist_max, tau, no_filter, multi, summarize)
+ *     IBatch::estimate_distances(std::stringstream&)          src/query.hpp:49-63
+ *
+ * constructed per 512-read batch on the reader thread and run inside an OpenMP
+ * task (src/krepp.cpp:365-383).  This header is that seam as a C ABI: plain
+ * pointers and sizes, no C++ or torch types.  Each entry point names the
+ * reference interface it replaces.  Every function returns 0 on success or a
+ * negative kr_status; kr_last_error() returns a per-thread message.
+ *
+ * Ownership: the caller owns every host buffer it passes in; the library owns
+ * all device memory and every buffer it returns (valid until the owning handle
+ * is destroyed or, for results, until the next submit on the same stream).
+ * A kr_index is immutable after upload and may be shared by any number of
+ * kr_stream objects; a kr_stream is used by one host thread at a time.
+ *
+ * There is NO CPU fallback: without a usable HIP device every device entry
+ * point returns KR_ERR_NO_DEVICE.
+ */
+#ifndef KREPP_AMD_H
+#define KREPP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KR_API __attribute__((visibility("default")))
+
+typedef enum kr_status {
+  KR_OK = 0,
+  KR_ERR_ARG = -1,        /* bad argument / unsupported configuration          */
+  KR_ERR_IO = -2,         /* index directory / file problems ([ERROR] paths of  */
+                          /* src/index.cpp:51-158, src/krepp.cpp:66-108)        */
+  KR_ERR_FORMAT = -3,     /* inconsistent index files, incompatible libraries  */
+  KR_ERR_NO_DEVICE = -4,  /* no HIP device / HIP runtime failure               */
+  KR_ERR_NOMEM = -5,
+  KR_ERR_CAPACITY = -6,   /* a device-side buffer overflowed; resubmit smaller  */
+  KR_ERR_STATE = -7       /* call order (collect without submit, ...)           */
+} kr_status;
+
+#define KR_MAX_HDIST_TH 16u /* k-h <= 16 (src/krepp.hpp:77-79): hd never exceeds 16 */
+
+/* ------------------------------------------------------------------------- */
+/* Host-side index: replaces TargetIndex::load_index (src/krepp.cpp:66-108),   */
+/* Index::load_partial_index / load_partial_tree / generate_partial_tree /     */
+/* make_rho_partial (src/index.cpp:3-158,188-201), FlatHT::load                */
+/* (src/table.cpp:65-75), CRecord::load (src/record.cpp:203-211), Tree::load   */
+/* and Node::parse / generate_tree (src/phytree.cpp:150-253,394-404).          */
+/* ------------------------------------------------------------------------- */
+typedef struct kr_host_index kr_host_index;
+
+/* One partial library as laid out on disk (little-endian, no padding). */
+typedef struct kr_lib_view {
+  const uint64_t* inc;   /* inc-*    payload: cumulative bucket END offsets [nrows]  */
+  const uint32_t* cmer;  /* cmer-*   payload: interleaved (enc32, se) [2*nkmers]     */
+  const uint32_t* pse;   /* crecord-* se_to_pse: interleaved (first, second) [2*nsubsets] */
+  const double* rho;     /* crecord-* se_to_rho [nnodes], already scaled by            */
+                         /* make_rho_partial's (#residues present)/m                    */
+  uint64_t nkmers;
+  uint32_t nrows;
+  uint32_t nsubsets;
+  uint32_t nnodes;       /* crecord's nnodes = tree nodes + 1                           */
+  uint32_t r;            /* metadata-* r                                                */
+  uint32_t frac;         /* metadata-* frac                                             */
+  uint32_t w;            /* metadata-* w (informational)                                */
+} kr_lib_view;
+
+typedef struct kr_index_view {
+  uint32_t k, h, m;
+  const uint8_t* ppos;       /* [h]   LSH positions, descending (metadata-*)           */
+  const uint8_t* npos;       /* [k-h] non-LSH positions, ascending                     */
+  uint32_t nlibs;
+  const kr_lib_view* libs;
+  uint32_t tree_nnodes;      /* Tree::nnodes; colour ids 1..tree_nnodes are tree nodes */
+  const uint8_t* node_kind;  /* [tree_nnodes+1] 0 = null (Tree::get_node == nullptr),  */
+                             /* 1 = leaf, 2 = internal (src/query.cpp:371-381)         */
+  uint32_t wbackbone;        /* Index::check_wbackbone                                 */
+} kr_index_view;
+
+KR_API int kr_host_index_load(const char* index_dir, kr_host_index** out);
+KR_API void kr_host_index_free(kr_host_index*);
+KR_API int kr_host_index_view(const kr_host_index*, kr_index_view* out);
+/* Node::get_name (src/phytree.hpp:134-145): label, or se-1 for unlabelled nodes. */
+KR_API const char* kr_host_index_node_name(const kr_host_index*, uint32_t se);
+KR_API uint32_t kr_host_index_node_parent(const kr_host_index*, uint32_t se);
+KR_API double kr_host_index_node_blen(const kr_host_index*, uint32_t se);
+
+/* ------------------------------------------------------------------------- */
+/* Device index: the read-only state IBatch borrows from Index                 */
+/* (Index::check_partial src/index.hpp:27, Index::bucket_indices               */
+/* src/index.cpp:160-168, Index::get_crecord :170, LSHF::compute_hash /        */
+/* drop_ppos_lr src/lshf.cpp:62-69).                                           */
+/* ------------------------------------------------------------------------- */
+typedef struct kr_index kr_index;
+
+#define KR_VIEW_HOST 0u
+#define KR_VIEW_DEVICE 1u /* the view's inc/cmer/pse/rho pointers are device pointers */
+
+/* Re-lays the on-disk arrays out for the GPU (DESIGN.md "HBM layout") in HBM of
+ * `device`.  With KR_VIEW_DEVICE the big arrays are read from device memory
+ * (ppos/npos/node_kind and the kr_lib_view structs themselves stay host). */
+KR_API int kr_index_upload(const kr_index_view* view, int device, uint32_t flags, kr_index** out);
+KR_API void kr_index_free(kr_index*);
+
+/* Flat device buffers of an uploaded index, for replication to other GPUs by
+ * whatever transport the host uses (RCCL broadcast from torch.distributed,
+ * hipMemcpyPeer, ...).  `desc` is a small host blob describing sizes and
+ * parameters; kr_index_import allocates the same buffers on another device and
+ * returns their addresses so the transport can fill them. */
+typedef struct kr_index_buffer {
+  void* dptr;
+  uint64_t bytes;
+} kr_index_buffer;
+KR_API int kr_index_export(const kr_index*, void* desc, uint64_t* desc_bytes, kr_index_buffer* bufs, uint32_t* nbufs);
+KR_API int kr_index_import(const void* desc, uint64_t desc_bytes, int device, kr_index** out, kr_index_buffer* bufs,
+                           uint32_t* nbufs);
+KR_API uint64_t kr_index_device_bytes(const kr_index*);
+
+/* ------------------------------------------------------------------------- */
+/* Query: IBatch ctor + IBatch::estimate_distances (src/query.cpp:8-38,        */
+/* 141-156): search_mers (:40-94), IMers::add_matching_mer (:352-390),         */
+/* Minfo::update_match (src/query.hpp:153-176), summarize_matches              */
+/* (src/query.cpp:96-139), Minfo::optimize_likelihood (:426-433) with          */
+/* HDistHistLLH (src/hdhistllh.hpp:51-96) and Boost's brent_find_minima, and   */
+/* the selection logic of report_distances (:158-196).                         */
+/* ------------------------------------------------------------------------- */
+typedef struct kr_params {
+  uint32_t hdist_th;   /* --hdist-th  [4]      (src/krepp.hpp:210)                */
+  uint32_t tau;        /* --tau       [2]      (place only; unused by dist)       */
+  double chisq;        /* --chisq     [2.706]                                     */
+  double dist_max;     /* --dist-max  [NaN = unset]                               */
+  uint32_t multi;      /* --multi     [1]                                         */
+  uint32_t no_filter;  /* !--filter   [1 for dist] (src/krepp.cpp:635-644)        */
+} kr_params;
+
+KR_API void kr_params_default(kr_params*);
+
+typedef struct kr_stream kr_stream;
+
+/* max_reads / max_bases bound one submitted batch; buffers are sized once. */
+KR_API int kr_stream_create(const kr_index*, const kr_params*, uint32_t max_reads, uint64_t max_bases,
+                            kr_stream** out);
+KR_API void kr_stream_destroy(kr_stream*);
+
+#define KR_BASES_HOST 0u
+#define KR_BASES_DEVICE 1u /* bases/offsets already resident in this device's HBM */
+#define KR_TAP_ACCS 2u     /* keep per-(read,strand,leaf) histograms for kr_batch_taps */
+#define KR_TAP_HITS 4u     /* record every table hit (debug; slow)                 */
+
+/* Queue one batch: `bases` = concatenated ASCII sequences exactly as the FASTX
+ * reader delivers them (QSeq::read_next_batch, src/rqseq.cpp:180-197),
+ * offsets[nreads+1] = start of each read.  Asynchronous: host buffers must stay
+ * valid until kr_batch_collect / kr_batch_wait returns. */
+KR_API int kr_batch_submit(kr_stream*, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads,
+                           uint32_t flags);
+KR_API int kr_batch_wait(kr_stream*);
+
+/* One candidate row = one (read, leaf): what report_distances iterates over. */
+typedef struct kr_result_view {
+  uint32_t nreads;
+  uint32_t nrecs;             /* (read, strand, leaf) accumulators that passed the       */
+                              /* hdist_filt test (src/query.cpp:106,119)                  */
+  const uint32_t* read_off;   /* [nreads] first record of the read                       */
+  const uint32_t* read_cnt;   /* [nreads] number of records of the read                  */
+  const uint32_t* read_onmers;/* [nreads] valid k-mer positions (src/query.cpp:66)       */
+  const uint8_t* read_na;     /* [nreads] 1 = the read gets the "NA\tNaN" row             */
+                              /* (src/query.cpp:173-176)                                 */
+  const uint32_t* rec_key;    /* [nrecs]  (se << 1) | strand; ascending inside a read    */
+  const uint8_t* rec_sel;     /* [nrecs]  1 = this record is an output row of `dist`     */
+  const double* rec_d;        /* [nrecs]  d_llh                                          */
+  const double* rec_v;        /* [nrecs]  v_llh                                          */
+  const double* rec_chisq;    /* [nrecs]  chi-square vs the closest (filter mode), else NaN */
+  const uint32_t* rec_hist;   /* [nrecs * (hdist_th+1)] with KR_TAP_ACCS, else NULL      */
+  uint64_t nrows;             /* number of rec_sel == 1                                  */
+} kr_result_view;
+
+/* Waits for the batch and copies results to pinned host memory owned by the stream. */
+KR_API int kr_batch_collect(kr_stream*, kr_result_view* out);
+/* As above but the arrays stay in HBM (device pointers); only counts are read back. */
+KR_API int kr_batch_collect_device(kr_stream*, kr_result_view* out);
+
+/* Debug taps (parity tests).  Hits: one entry per table entry with hd <= hdist_th. */
+typedef struct kr_hit {
+  uint32_t read;
+  uint32_t kpos;    /* k-mer start index in the read                               */
+  uint32_t strand;
+  uint32_t lib;
+  uint64_t cmer_index;
+  uint32_t hd;
+  uint32_t se;
+} kr_hit;
+KR_API int kr_batch_hits(kr_stream*, const kr_hit** hits, uint64_t* nhits);
+typedef struct kr_readtap {
+  uint32_t hdist_filt[2]; /* per-strand min hd over kept entries, 0xFFFFFFFF = none */
+} kr_readtap;
+KR_API int kr_batch_readtaps(kr_stream*, const kr_readtap** taps);
+
+/* Front-end tap: rix / enc32 / residue test for every (k-mer, strand) of one batch,
+ * laid out [read][kpos][strand] with `stride` = max k-mers per read; valid==0 marks
+ * positions whose window holds a non-ACGT byte or runs past the read. */
+KR_API int kr_debug_front_end(const kr_index*, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads,
+                              uint32_t stride, uint32_t* rix, uint32_t* enc32, uint8_t* valid, uint8_t* pass);
+
+/* Likelihood + minimiser on their own (device): one problem per element. */
+KR_API int kr_debug_brent(const kr_index*, uint32_t hdist_th, uint32_t n, const uint32_t* hist /*[n*(th+1)]*/,
+                          const uint32_t* onmers, const double* rho, double* d_out, double* v_out);
+
+/* Kernel timing of the last collected batch (HIP events on the stream's own stream). */
+typedef struct kr_timing {
+  float ms_total;    /* first kernel start -> last kernel end                        */
+  float ms_probe;    /* probe/expand/accumulate kernel(s) (dominant)                 */
+  float ms_llh;      /* likelihood + selection kernels                               */
+  float ms_h2d;      /* host->device copies (0 with KR_BASES_DEVICE)                 */
+  uint32_t overflow_reads; /* reads that took the global-memory accumulator path     */
+  uint32_t pad;
+} kr_timing;
+KR_API int kr_batch_timing(kr_stream*, kr_timing* out);
+
+/* ------------------------------------------------------------------------- */
+/* Host helpers mirroring the reference's reader and writer.                    */
+/* ------------------------------------------------------------------------- */
+/* QSeq (src/rqseq.cpp:146-203): gz/FASTA/FASTQ batches of >= 76,800 bases.       */
+typedef struct kr_fastx kr_fastx;
+typedef struct kr_fastx_batch {
+  const uint8_t* bases;
+  const uint64_t* offsets;     /* [nreads+1] */
+  const char* const* names;    /* [nreads]   */
+  uint32_t nreads;
+  uint32_t more;               /* 0 once the input is exhausted                    */
+} kr_fastx_batch;
+KR_API int kr_fastx_open(const char* path, kr_fastx** out);
+KR_API int kr_fastx_next(kr_fastx*, uint64_t min_bases, kr_fastx_batch* out);
+KR_API void kr_fastx_close(kr_fastx*);
+
+/* report_distances text (src/query.cpp:158-196; DISTANCE_FIELDS src/query.hpp:210;
+ * std::fixed, precision 5 src/query.cpp:152-153).  Appends to a malloc'ed buffer. */
+KR_API int kr_format_dist(const kr_host_index*, const kr_result_view*, const char* const* names, char** text,
+                          uint64_t* len);
+KR_API void kr_free(void*);
+
+/* CPU-side index construction (`krepp index`, src/krepp.cpp:131-303): stays on the
+ * CPU as in the reference; needed to make any index at all. */
+typedef struct kr_build_params {
+  uint32_t k, w, h, m, r, frac; /* defaults 29, 35, 13, 4, 1, 1 (src/krepp.hpp:47-58) */
+  uint32_t num_threads;
+  uint32_t seed;
+  const uint8_t* ppos;          /* optional explicit LSH positions [h] (descending)    */
+} kr_build_params;
+KR_API int kr_build_index(const char* input_tsv, const char* nwk_path /*may be NULL*/, const char* out_dir,
+                          const kr_build_params*);
+
+KR_API const char* kr_last_error(void);
+KR_API const char* kr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,439 @@
+"""ctypes binding of include/krepp_amd.h (the C ABI of the MI355X `krepp dist` path).
+
+This module is plumbing only: it loads ``krepp_amd/lib/libkrepp_amd.so`` (built by
+``__graft_entry__.build()`` / ``krepp_amd/csrc/Makefile``) and fails loudly if it is
+missing.  There is no Python or CPU fallback for any device entry point.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libkrepp_amd.so"
+
+KR_OK = 0
+KR_ERR_ARG, KR_ERR_IO, KR_ERR_FORMAT, KR_ERR_NO_DEVICE = -1, -2, -3, -4
+KR_ERR_NOMEM, KR_ERR_CAPACITY, KR_ERR_STATE = -5, -6, -7
+KR_VIEW_HOST, KR_VIEW_DEVICE = 0, 1
+KR_BASES_HOST, KR_BASES_DEVICE, KR_TAP_ACCS, KR_TAP_HITS = 0, 1, 2, 4
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+f64p = C.POINTER(C.c_double)
+
+
+class KrLibView(C.Structure):
+    _fields_ = [("inc", u64p), ("cmer", u32p), ("pse", u32p), ("rho", f64p),
+                ("nkmers", C.c_uint64), ("nrows", C.c_uint32), ("nsubsets", C.c_uint32),
+                ("nnodes", C.c_uint32), ("r", C.c_uint32), ("frac", C.c_uint32), ("w", C.c_uint32)]
+
+
+class KrIndexView(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("h", C.c_uint32), ("m", C.c_uint32),
+                ("ppos", u8p), ("npos", u8p), ("nlibs", C.c_uint32), ("libs", C.POINTER(KrLibView)),
+                ("tree_nnodes", C.c_uint32), ("node_kind", u8p), ("wbackbone", C.c_uint32)]
+
+
+class KrIndexBuffer(C.Structure):
+    _fields_ = [("dptr", C.c_void_p), ("bytes", C.c_uint64)]
+
+
+class KrParams(C.Structure):
+    _fields_ = [("hdist_th", C.c_uint32), ("tau", C.c_uint32), ("chisq", C.c_double),
+                ("dist_max", C.c_double), ("multi", C.c_uint32), ("no_filter", C.c_uint32)]
+
+
+class KrResultView(C.Structure):
+    _fields_ = [("nreads", C.c_uint32), ("nrecs", C.c_uint32),
+                ("read_off", u32p), ("read_cnt", u32p), ("read_onmers", u32p), ("read_na", u8p),
+                ("rec_key", u32p), ("rec_sel", u8p), ("rec_d", f64p), ("rec_v", f64p),
+                ("rec_chisq", f64p), ("rec_hist", u32p), ("nrows", C.c_uint64)]
+
+
+class KrHit(C.Structure):
+    _fields_ = [("read", C.c_uint32), ("kpos", C.c_uint32), ("strand", C.c_uint32), ("lib", C.c_uint32),
+                ("cmer_index", C.c_uint64), ("hd", C.c_uint32), ("se", C.c_uint32)]
+
+
+class KrTiming(C.Structure):
+    _fields_ = [("ms_total", C.c_float), ("ms_probe", C.c_float), ("ms_llh", C.c_float), ("ms_h2d", C.c_float),
+                ("overflow_reads", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class KrFastxBatch(C.Structure):
+    _fields_ = [("bases", u8p), ("offsets", u64p), ("names", C.POINTER(C.c_char_p)),
+                ("nreads", C.c_uint32), ("more", C.c_uint32)]
+
+
+class KrBuildParams(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32), ("m", C.c_uint32), ("r", C.c_uint32),
+                ("frac", C.c_uint32), ("num_threads", C.c_uint32), ("seed", C.c_uint32), ("ppos", u8p)]
+
+
+# every symbol include/krepp_amd.h declares (tests check that the library exports them all)
+EXPORTS = [
+    "kr_host_index_load", "kr_host_index_free", "kr_host_index_view", "kr_host_index_node_name",
+    "kr_host_index_node_parent", "kr_host_index_node_blen",
+    "kr_index_upload", "kr_index_free", "kr_index_export", "kr_index_import", "kr_index_device_bytes",
+    "kr_params_default", "kr_stream_create", "kr_stream_destroy", "kr_batch_submit", "kr_batch_wait",
+    "kr_batch_collect", "kr_batch_collect_device", "kr_batch_hits", "kr_batch_readtaps",
+    "kr_debug_front_end", "kr_debug_brent", "kr_batch_timing",
+    "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_format_dist", "kr_free",
+    "kr_build_index", "kr_last_error", "kr_version",
+]
+
+_lib = None
+
+
+class KrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"krepp_amd error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """Load libkrepp_amd.so; raise if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the HIP extension is required; there is no CPU fallback)")
+    lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
+    vp = C.c_void_p
+    lib.kr_last_error.restype = C.c_char_p
+    lib.kr_version.restype = C.c_char_p
+    lib.kr_host_index_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.kr_host_index_free.argtypes = [vp]
+    lib.kr_host_index_free.restype = None
+    lib.kr_host_index_view.argtypes = [vp, C.POINTER(KrIndexView)]
+    lib.kr_host_index_node_name.argtypes = [vp, C.c_uint32]
+    lib.kr_host_index_node_name.restype = C.c_char_p
+    lib.kr_host_index_node_parent.argtypes = [vp, C.c_uint32]
+    lib.kr_host_index_node_parent.restype = C.c_uint32
+    lib.kr_host_index_node_blen.argtypes = [vp, C.c_uint32]
+    lib.kr_host_index_node_blen.restype = C.c_double
+    lib.kr_index_upload.argtypes = [C.POINTER(KrIndexView), C.c_int, C.c_uint32, C.POINTER(vp)]
+    lib.kr_index_free.argtypes = [vp]
+    lib.kr_index_free.restype = None
+    lib.kr_index_export.argtypes = [vp, vp, u64p, C.POINTER(KrIndexBuffer), u32p]
+    lib.kr_index_import.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(vp), C.POINTER(KrIndexBuffer), u32p]
+    lib.kr_index_device_bytes.argtypes = [vp]
+    lib.kr_index_device_bytes.restype = C.c_uint64
+    lib.kr_params_default.argtypes = [C.POINTER(KrParams)]
+    lib.kr_params_default.restype = None
+    lib.kr_stream_create.argtypes = [vp, C.POINTER(KrParams), C.c_uint32, C.c_uint64, C.POINTER(vp)]
+    lib.kr_stream_destroy.argtypes = [vp]
+    lib.kr_stream_destroy.restype = None
+    lib.kr_batch_submit.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32]
+    lib.kr_batch_wait.argtypes = [vp]
+    lib.kr_batch_collect.argtypes = [vp, C.POINTER(KrResultView)]
+    lib.kr_batch_collect_device.argtypes = [vp, C.POINTER(KrResultView)]
+    lib.kr_batch_hits.argtypes = [vp, C.POINTER(C.POINTER(KrHit)), u64p]
+    lib.kr_batch_readtaps.argtypes = [vp, C.POINTER(u32p)]
+    lib.kr_debug_front_end.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
+    lib.kr_debug_brent.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]
+    lib.kr_batch_timing.argtypes = [vp, C.POINTER(KrTiming)]
+    lib.kr_fastx_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.kr_fastx_next.argtypes = [vp, C.c_uint64, C.POINTER(KrFastxBatch)]
+    lib.kr_fastx_close.argtypes = [vp]
+    lib.kr_fastx_close.restype = None
+    lib.kr_format_dist.argtypes = [vp, C.POINTER(KrResultView), C.POINTER(C.c_char_p), C.POINTER(vp), u64p]
+    lib.kr_free.argtypes = [vp]
+    lib.kr_free.restype = None
+    lib.kr_build_index.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(KrBuildParams)]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != KR_OK:
+        raise KrError(rc, load().kr_last_error().decode(errors="replace"))
+
+
+def _np(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(int(n),)).view(dtype).copy()
+
+
+class HostIndex:
+    """Index directory read into host memory (reference: TargetIndex::load_index, src/krepp.cpp:66-108)."""
+
+    def __init__(self, index_dir):
+        self.lib = load()
+        self.h = C.c_void_p()
+        check(self.lib.kr_host_index_load(os.fsencode(str(index_dir)), C.byref(self.h)))
+        self.view = KrIndexView()
+        check(self.lib.kr_host_index_view(self.h, C.byref(self.view)))
+
+    k = property(lambda s: s.view.k)
+    hh = property(lambda s: s.view.h)
+    m = property(lambda s: s.view.m)
+    nnodes = property(lambda s: s.view.tree_nnodes)
+
+    def name(self, se):
+        return self.lib.kr_host_index_node_name(self.h, int(se)).decode()
+
+    def parent(self, se):
+        return int(self.lib.kr_host_index_node_parent(self.h, int(se)))
+
+    def blen(self, se):
+        return float(self.lib.kr_host_index_node_blen(self.h, int(se)))
+
+    def kinds(self):
+        return _np(self.view.node_kind, self.view.tree_nnodes + 1, np.uint8)
+
+    def positions(self):
+        return _np(self.view.ppos, self.view.h, np.uint8), _np(self.view.npos, self.view.k - self.view.h, np.uint8)
+
+    def lib_arrays(self, i=0):
+        lv = self.view.libs[i]
+        return dict(inc=_np(lv.inc, lv.nrows, np.uint64), cmer=_np(lv.cmer, 2 * lv.nkmers, np.uint32).reshape(-1, 2),
+                    pse=_np(lv.pse, 2 * lv.nsubsets, np.uint32).reshape(-1, 2), rho=_np(lv.rho, lv.nnodes, np.float64),
+                    r=lv.r, frac=lv.frac, w=lv.w, nnodes=lv.nnodes, nsubsets=lv.nsubsets)
+
+    def upload(self, device=0):
+        return DeviceIndex.from_view(self.view, device, KR_VIEW_HOST, keep=self)
+
+    def close(self):
+        if self.h:
+            self.lib.kr_host_index_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def default_params(**kw):
+    p = KrParams()
+    load().kr_params_default(C.byref(p))
+    for k_, v in kw.items():
+        setattr(p, k_, v)
+    return p
+
+
+class DeviceIndex:
+    """Index resident in one GPU's HBM (the read-only state IBatch borrows from Index)."""
+
+    def __init__(self, handle, keep=None):
+        self.lib = load()
+        self.h = handle
+        self._keep = keep
+
+    @classmethod
+    def from_view(cls, view, device=0, flags=KR_VIEW_HOST, keep=None):
+        lib = load()
+        h = C.c_void_p()
+        check(lib.kr_index_upload(C.byref(view), int(device), int(flags), C.byref(h)))
+        return cls(h, keep)
+
+    def export(self):
+        """(descriptor bytes, [(device pointer, bytes), ...]) of the flat buffers, for replication."""
+        nb = C.c_uint64(0)
+        n = C.c_uint32(0)
+        check(self.lib.kr_index_export(self.h, None, C.byref(nb), None, C.byref(n)))
+        desc = C.create_string_buffer(nb.value)
+        bufs = (KrIndexBuffer * n.value)()
+        check(self.lib.kr_index_export(self.h, desc, C.byref(nb), bufs, C.byref(n)))
+        return desc.raw, [(b.dptr, b.bytes) for b in bufs]
+
+    @classmethod
+    def import_empty(cls, desc, device=0):
+        """Allocate the buffers described by `desc` on `device`; the caller fills them."""
+        lib = load()
+        h = C.c_void_p()
+        n = C.c_uint32(256)
+        bufs = (KrIndexBuffer * 256)()
+        check(lib.kr_index_import(desc, len(desc), int(device), C.byref(h), bufs, C.byref(n)))
+        return cls(h), [(bufs[i].dptr, bufs[i].bytes) for i in range(n.value)]
+
+    @property
+    def device_bytes(self):
+        return int(self.lib.kr_index_device_bytes(self.h))
+
+    def stream(self, params=None, max_reads=1 << 16, max_bases=None):
+        return Stream(self, params or default_params(), max_reads, max_bases or max_reads * 160)
+
+    def front_end(self, bases, offsets, stride):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        rix = np.zeros((n, stride, 2), np.uint32)
+        enc = np.zeros((n, stride, 2), np.uint32)
+        valid = np.zeros((n, stride, 2), np.uint8)
+        pas = np.zeros((n, stride, 2), np.uint8)
+        check(self.lib.kr_debug_front_end(self.h, bases.ctypes.data, offsets.ctypes.data, n, stride,
+                                          rix.ctypes.data, enc.ctypes.data, valid.ctypes.data, pas.ctypes.data))
+        return rix, enc, valid, pas
+
+    def brent(self, th, hist, onmers, rho):
+        hist = np.ascontiguousarray(hist, dtype=np.uint32)
+        onmers = np.ascontiguousarray(onmers, dtype=np.uint32)
+        rho = np.ascontiguousarray(rho, dtype=np.float64)
+        n = len(onmers)
+        d = np.zeros(n)
+        v = np.zeros(n)
+        check(self.lib.kr_debug_brent(self.h, th, n, hist.ctypes.data, onmers.ctypes.data, rho.ctypes.data,
+                                      d.ctypes.data, v.ctypes.data))
+        return d, v
+
+    def close(self):
+        if self.h:
+            self.lib.kr_index_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Result:
+    """Host copy of one batch's results (see kr_result_view)."""
+
+    def __init__(self, rv, np_planes, copy_hist):
+        n, c = rv.nreads, rv.nrecs
+        self.nreads, self.nrecs, self.nrows = n, c, int(rv.nrows)
+        self.read_off = _np(rv.read_off, n, np.uint32)
+        self.read_cnt = _np(rv.read_cnt, n, np.uint32)
+        self.read_onmers = _np(rv.read_onmers, n, np.uint32)
+        self.read_na = _np(rv.read_na, n, np.uint8)
+        self.rec_key = _np(rv.rec_key, c, np.uint32)
+        self.rec_sel = _np(rv.rec_sel, c, np.uint8)
+        self.rec_d = _np(rv.rec_d, c, np.float64)
+        self.rec_v = _np(rv.rec_v, c, np.float64)
+        self.rec_chisq = _np(rv.rec_chisq, c, np.float64)
+        self.rec_hist = _np(rv.rec_hist, c * np_planes, np.uint32).reshape(-1, np_planes) if copy_hist and rv.rec_hist else None
+        # read index of every record
+        self.rec_read = np.zeros(c, np.uint32)
+        for r in np.nonzero(self.read_cnt)[0]:
+            self.rec_read[self.read_off[r]:self.read_off[r] + self.read_cnt[r]] = r
+
+    def rows(self):
+        """Sorted list of (read, se, d) output rows — `krepp dist` rows as a set."""
+        sel = self.rec_sel.astype(bool)
+        return sorted(zip(self.rec_read[sel].tolist(), (self.rec_key[sel] >> 1).tolist(), self.rec_d[sel].tolist()))
+
+
+class Stream:
+    def __init__(self, dindex, params, max_reads, max_bases):
+        self.lib = load()
+        self.ix = dindex
+        self.params = params
+        self.h = C.c_void_p()
+        check(self.lib.kr_stream_create(dindex.h, C.byref(params), int(max_reads), int(max_bases), C.byref(self.h)))
+        self._keep = None
+        self._flags = 0
+
+    def submit(self, bases, offsets, flags=0):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._keep = (bases, offsets)
+        self._flags = flags
+        check(self.lib.kr_batch_submit(self.h, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, flags))
+
+    def submit_device(self, bases_ptr, offsets_ptr, nreads, flags=0):
+        self._flags = flags | KR_BASES_DEVICE
+        check(self.lib.kr_batch_submit(self.h, int(bases_ptr), int(offsets_ptr), int(nreads), self._flags))
+
+    def wait(self):
+        check(self.lib.kr_batch_wait(self.h))
+
+    def collect(self):
+        rv = KrResultView()
+        check(self.lib.kr_batch_collect(self.h, C.byref(rv)))
+        self._rv = rv
+        return Result(rv, self.params.hdist_th + 1, bool(self._flags & KR_TAP_ACCS))
+
+    def collect_device(self):
+        rv = KrResultView()
+        check(self.lib.kr_batch_collect_device(self.h, C.byref(rv)))
+        return rv
+
+    def hits(self):
+        p = C.POINTER(KrHit)()
+        n = C.c_uint64()
+        check(self.lib.kr_batch_hits(self.h, C.byref(p), C.byref(n)))
+        dt = np.dtype([("read", "<u4"), ("kpos", "<u4"), ("strand", "<u4"), ("lib", "<u4"), ("cmer_index", "<u8"),
+                       ("hd", "<u4"), ("se", "<u4")])
+        if n.value == 0:
+            return np.zeros(0, dt)
+        raw = C.string_at(p, n.value * C.sizeof(KrHit))
+        return np.frombuffer(raw, dtype=dt).copy()
+
+    def readtaps(self, nreads):
+        p = u32p()
+        check(self.lib.kr_batch_readtaps(self.h, C.byref(p)))
+        return _np(p, 2 * nreads, np.uint32).reshape(-1, 2)
+
+    def timing(self):
+        t = KrTiming()
+        check(self.lib.kr_batch_timing(self.h, C.byref(t)))
+        return t
+
+    def format_dist(self, host_index, names):
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        txt = C.c_void_p()
+        ln = C.c_uint64()
+        check(self.lib.kr_format_dist(host_index.h, C.byref(self._rv), arr, C.byref(txt), C.byref(ln)))
+        s = C.string_at(txt, ln.value).decode()
+        self.lib.kr_free(txt)
+        return s
+
+    def close(self):
+        if self.h:
+            self.lib.kr_stream_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def read_fastx(path, min_bases=76800):
+    """All records of a FASTA/FASTQ(.gz) file via the library's reader: (names, bases, offsets)."""
+    lib = load()
+    h = C.c_void_p()
+    check(lib.kr_fastx_open(os.fsencode(str(path)), C.byref(h)))
+    names, chunks, lens = [], [], []
+    try:
+        while True:
+            b = KrFastxBatch()
+            check(lib.kr_fastx_next(h, min_bases, C.byref(b)))
+            if b.nreads:
+                offs = np.ctypeslib.as_array(b.offsets, shape=(b.nreads + 1,)).copy()
+                chunks.append(np.ctypeslib.as_array(b.bases, shape=(int(offs[-1]),)).copy() if offs[-1] else np.zeros(0, np.uint8))
+                lens.extend(np.diff(offs).tolist())
+                names.extend(b.names[i].decode() for i in range(b.nreads))
+            if not b.more:
+                break
+    finally:
+        lib.kr_fastx_close(h)
+    bases = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
+    offsets = np.zeros(len(lens) + 1, np.uint64)
+    offsets[1:] = np.cumsum(np.asarray(lens, dtype=np.uint64))
+    return names, bases, offsets
+
+
+def build_index(input_tsv, out_dir, nwk=None, k=29, w=35, h=13, m=4, r=1, frac=True, num_threads=1, seed=0, ppos=None):
+    """`krepp index` on the CPU (reference: src/krepp.cpp:131-303)."""
+    lib = load()
+    p = KrBuildParams(k=k, w=w, h=h, m=m, r=r, frac=int(frac), num_threads=num_threads, seed=seed, ppos=None)
+    keep = None
+    if ppos is not None:
+        keep = (C.c_uint8 * len(ppos))(*ppos)
+        p.ppos = C.cast(keep, u8p)
+    check(lib.kr_build_index(os.fsencode(str(input_tsv)), os.fsencode(str(nwk)) if nwk else None,
+                             os.fsencode(str(out_dir)), C.byref(p)))

@@ -1,0 +1,1716 @@
+// kr_device.hip — the per-read `krepp dist` hot path as hand-written HIP for gfx950
+// (MI355X), and the device half of the C ABI (include/krepp_amd.h).
+//
+// Pipeline per submitted batch (one HIP stream per kr_stream):
+//
+//   kr_probe_kernel      one wave64 per read.  Front end from wave ballots (no LDS, no
+//                        rolling state): every k-mer x strand -> LSH row (rix) and
+//                        residual code (enc32)          [src/query.cpp:40-94,
+//                        src/common.hpp:177-243, src/lshf.cpp:39-69]; bucket lookup
+//                        [src/index.cpp:160-168]; bucket scan with lanes flattened over
+//                        16-byte chunks of the bucket, Hamming filter
+//                        [src/query.cpp:361-368]; colour-DAG expansion from an LDS work
+//                        stack [src/query.cpp:369-387]; per-(strand, leaf) accumulation
+//                        as position bit-planes in an LDS hash table
+//                        [Minfo::update_match, src/query.hpp:153-176]; hdist_filt test
+//                        [src/query.cpp:101-106,119] and record emission.
+//   kr_probe_overflow_kernel  same code, accumulator table in global memory, for reads
+//                        whose leaf set does not fit the LDS table.
+//   kr_llh_kernel        one lane per (read, strand, leaf) record: Brent minimisation of
+//                        HDistHistLLH in fp64 [src/hdhistllh.hpp:51-96,
+//                        src/query.cpp:426-433, boost::math::tools::brent_find_minima].
+//   kr_select_kernel     one lane per read: strand merge, closest reference, --filter /
+//                        --dist-max / --no-multi selection [src/query.cpp:96-139,158-196].
+//
+// Exactness: Minfo::update_match counts, per read position, only the smallest Hamming
+// distance among all hits that reach a leaf.  Here a hit sets bit `pos` in plane `hd` of
+// the (strand, leaf) accumulator with an atomic OR; at the end
+//     hist[x] = popcount(plane_x & ~(plane_0 | ... | plane_{x-1})).
+// OR is idempotent and commutative, so the result does not depend on the order in which
+// lanes, probes or colour expansions arrive, and is bit-identical to the serial rule.
+//
+// Built with -ffp-contract=off: the reference is compiled for baseline x86-64 (no FMA,
+// makefile:7), and the likelihood follows its operation order.
+#include <hip/hip_runtime.h>
+
+#include "kr_common.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Compile-time shape of the probe kernel
+// ---------------------------------------------------------------------------
+constexpr int kWave = 64;
+constexpr int kSegPos = 128;      // k-mer positions per segment = 4 plane words
+constexpr int kPlaneWords = kSegPos / 32;
+constexpr int kMaxRuns = 16;
+constexpr int kMaxLibs = 16;
+constexpr int kStackCap = 512;    // colour work stack (items of 8 B)
+constexpr int kLdsSlots = 64;     // LDS accumulator table entries per wave
+constexpr int kMaxPlanes = KR_MAX_HDIST_TH + 1;
+
+struct Runs {
+  uint32_t n;
+  uint8_t src[kMaxRuns], len[kMaxRuns], dst[kMaxRuns];
+};
+
+struct DevLib {
+  const uint64_t* bkt;  // [nrows]  (start << 24) | len
+  const uint32_t* enc;  // [nkmers + pad] residual codes, bucket-contiguous
+  const uint32_t* se;   // [nkmers] colour ids
+  const uint2* pse;     // [nsubsets] colour DAG: colour = union of .x and .y
+  const double* rho;    // [nnodes] subsampling rates, already scaled
+  uint64_t nkmers;
+  uint32_t nrows, nsubsets, nnodes, numer;
+};
+
+struct DevIndex {
+  uint32_t k, h, m, nlibs, tree_nnodes;
+  uint32_t m_shift;      // log2(m) if m is a power of two, else 0xFFFFFFFF
+  Runs prun, nrun;       // contiguous runs of the LSH / non-LSH position lists
+  const uint8_t* kind;   // [tree_nnodes+1] 0 null, 1 leaf, 2 internal
+  const int32_t* res_lib; // [m] library serving each residue, or -1
+  const DevLib* libs;    // [nlibs] in device memory
+};
+
+struct LlhConst {
+  uint32_t k, h, th, pad;
+  double binom_k[32];
+  double binom_hnk[kMaxPlanes];
+};
+
+struct DevParams {
+  uint32_t th, np;       // np = th + 1 planes
+  uint32_t multi, no_filter, dmax_set, pad;
+  double chisq, dist_max;
+};
+
+// Everything the kernels write for one batch.
+struct BatchOut {
+  uint32_t* counters;    // [0] nrec  [1] error flags  [2] n overflow reads  [3] nhits(tap)
+  uint32_t* rd_off;
+  uint32_t* rd_cnt;
+  uint32_t* rd_onmers;
+  uint32_t* rd_filt;     // [2*nreads] raw per-strand hdist_filt (tap)
+  uint8_t* rd_na;
+  uint32_t* rec_read;
+  uint32_t* rec_key;
+  uint32_t* rec_hist;    // [rec_cap * np]
+  double* rec_d;
+  double* rec_v;
+  double* rec_chisq;
+  uint8_t* rec_sel;
+  uint32_t rec_cap;
+  uint32_t* ovf_list;    // reads to redo with the global table
+  kr_hit* hits;
+  uint32_t hit_cap;
+  // global accumulator scratch for the overflow kernel
+  uint32_t* g_keys;      // [nwaves * g_slots]
+  uint32_t* g_planes;    // [nwaves * g_slots * np * 4]
+  uint32_t* g_counts;    // [nwaves * g_slots * np]
+  uint32_t* g_touched;   // [nwaves * g_slots]
+  uint32_t g_slots;      // power of two
+};
+
+enum : uint32_t { kErrRecCap = 1u, kErrStack = 2u, kErrTable = 4u, kErrHitCap = 8u };
+
+struct BatchIn {
+  const uint8_t* bases;
+  const uint64_t* offsets;
+  uint32_t nreads;
+};
+
+// ---------------------------------------------------------------------------
+// Device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+__device__ __forceinline__ uint32_t pext_runs(uint32_t v, const Runs& r)
+{
+  uint32_t out = 0;
+  for (uint32_t i = 0; i < r.n; ++i) out |= ((v >> r.src[i]) & ((1u << r.len[i]) - 1u)) << r.dst[i];
+  return out;
+}
+
+// 16 -> 32 bit spread: bit j of v moves to bit 2j
+__device__ __forceinline__ uint32_t spread16(uint32_t v)
+{
+  v = (v | (v << 8)) & 0x00FF00FFu;
+  v = (v | (v << 4)) & 0x0F0F0F0Fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+
+// seq_nt4_table (src/common.cpp:10-14): 0..3 for ACGT/acgt, 4 otherwise
+__device__ __forceinline__ uint32_t base_code(uint32_t c)
+{
+  uint32_t u = c & 0xDFu; // fold case
+  uint32_t code = 4;
+  code = (u == 'A') ? 0u : code;
+  code = (u == 'C') ? 1u : code;
+  code = (u == 'G') ? 2u : code;
+  code = (u == 'T') ? 3u : code;
+  return (c & 0x80u) ? 4u : code;
+}
+
+// hd = number of non-LSH positions that differ (popcount_lr32, src/common.hpp:175)
+__device__ __forceinline__ uint32_t hd_lr32(uint32_t a, uint32_t b)
+{
+  uint32_t z = a ^ b;
+  return __popc((z | (z >> 16)) & 0xFFFFu);
+}
+
+__device__ __forceinline__ uint32_t hash_key(uint32_t key) { return key * 0x9E3779B1u; }
+
+// Per-(k-mer, strand) front end shared by the probe kernel and the debug tap.
+struct FrontEnd {
+  uint32_t rix[2], enc32[2]; // [strand]
+  bool valid;
+};
+
+// Three 64-bit ballots per bit array cover 192 bases of the segment; position j's window
+// is bits [j, j+k) in read order.
+struct SegBits {
+  uint64_t L[3], H[3], N[3];
+};
+
+__device__ __forceinline__ void load_segment(const uint8_t* seq, uint64_t len, uint64_t base0, SegBits& sb)
+{
+  uint32_t lane = lane_id();
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    uint64_t bi = base0 + 64u * p + lane;
+    uint32_t code = 4;
+    if (bi < len) code = base_code(seq[bi]);
+    sb.L[p] = __ballot(code & 1u && code < 4);
+    sb.H[p] = __ballot((code >> 1) & 1u && code < 4);
+    sb.N[p] = __ballot(code >= 4);
+  }
+}
+
+__device__ __forceinline__ uint32_t window32(uint64_t w0, uint64_t w1, uint32_t s)
+{
+  uint64_t v = s ? ((w0 >> s) | (w1 << (64 - s))) : w0;
+  return (uint32_t)v;
+}
+
+// pp = 0/1: positions j = 64*pp + lane of the segment.
+__device__ __forceinline__ FrontEnd front_end(const DevIndex& ix, const SegBits& sb, int pp, uint32_t npos_seg)
+{
+  FrontEnd fe;
+  uint32_t lane = lane_id();
+  uint32_t j = 64u * pp + lane;
+  uint32_t mk = (1u << ix.k) - 1u;
+  uint32_t wl = window32(sb.L[pp], sb.L[pp + 1], lane) & mk;
+  uint32_t wh = window32(sb.H[pp], sb.H[pp + 1], lane) & mk;
+  uint32_t wn = window32(sb.N[pp], sb.N[pp + 1], lane) & mk;
+  fe.valid = (wn == 0) && (j < npos_seg);
+  // position p of the k-mer counts from its LAST base
+  uint32_t lo_f = __brev(wl) >> (32 - ix.k), hi_f = __brev(wh) >> (32 - ix.k);
+  uint32_t lo_r = ~wl & mk, hi_r = ~wh & mk; // reverse complement: complement, order already reversed
+  fe.rix[0] = spread16(pext_runs(lo_f, ix.prun)) | (spread16(pext_runs(hi_f, ix.prun)) << 1);
+  fe.rix[1] = spread16(pext_runs(lo_r, ix.prun)) | (spread16(pext_runs(hi_r, ix.prun)) << 1);
+  fe.enc32[0] = pext_runs(lo_f, ix.nrun) | (pext_runs(hi_f, ix.nrun) << 16);
+  fe.enc32[1] = pext_runs(lo_r, ix.nrun) | (pext_runs(hi_r, ix.nrun) << 16);
+  return fe;
+}
+
+// Index::check_partial + Index::bucket_indices (src/index.hpp:27, src/index.cpp:160-168)
+__device__ __forceinline__ bool locate_row(const DevIndex& ix, uint32_t rix, int& lib, uint32_t& row)
+{
+  uint32_t res, q;
+  if (ix.m_shift != 0xFFFFFFFFu) {
+    res = rix & (ix.m - 1u);
+    q = rix >> ix.m_shift;
+  } else {
+    q = rix / ix.m;
+    res = rix - q * ix.m;
+  }
+  lib = ix.res_lib[res];
+  if (lib < 0) return false;
+  uint32_t numer = ix.libs[lib].numer;
+  row = numer > 1 ? q * numer + res : q;
+  return row < ix.libs[lib].nrows;
+}
+
+// ---------------------------------------------------------------------------
+// Accumulator table.  GT = false: LDS (ds_ atomics); GT = true: global scratch with
+// agent-scope atomics (L2), reads bypass the per-CU L1.
+// ---------------------------------------------------------------------------
+template <bool GT>
+struct Table {
+  uint32_t* keys;
+  uint32_t* planes;
+  uint32_t* counts;
+  uint32_t* touched; // GT only
+  uint32_t* ntouched; // GT only (LDS word)
+  uint32_t mask;     // slots - 1
+  uint32_t np;
+
+  __device__ __forceinline__ uint32_t load_key(uint32_t s) const
+  {
+    if (GT) return __hip_atomic_load(&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ((volatile uint32_t*)keys)[s];
+  }
+  __device__ __forceinline__ uint32_t cas_key(uint32_t s, uint32_t key) const
+  {
+    if (GT) {
+      uint32_t expected = 0;
+      __hip_atomic_compare_exchange_strong(&keys[s], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+      return expected;
+    }
+    return atomicCAS(&keys[s], 0u, key);
+  }
+  // returns slot or -1 when the table is full
+  __device__ __forceinline__ int find_or_insert(uint32_t key) const
+  {
+    uint32_t s = (hash_key(key) >> 8) & mask;
+    for (uint32_t i = 0; i <= mask; ++i) {
+      uint32_t cur = load_key(s);
+      if (cur == key) return (int)s;
+      if (cur == 0) {
+        uint32_t old = cas_key(s, key);
+        if (old == 0) {
+          if (GT) {
+            uint32_t t = atomicAdd(ntouched, 1u);
+            touched[t] = s;
+          }
+          return (int)s;
+        }
+        if (old == key) return (int)s;
+      }
+      s = (s + 1) & mask;
+    }
+    return -1;
+  }
+  __device__ __forceinline__ void or_bit(int slot, uint32_t hd, uint32_t pos) const
+  {
+    uint32_t* w = &planes[((uint32_t)slot * np + hd) * kPlaneWords + (pos >> 5)];
+    uint32_t bit = 1u << (pos & 31);
+    if (GT)
+      __hip_atomic_fetch_or(w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      atomicOr(w, bit);
+  }
+  __device__ __forceinline__ uint32_t load_plane(uint32_t i) const
+  {
+    if (GT) return __hip_atomic_load(&planes[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return planes[i];
+  }
+  __device__ __forceinline__ void store_plane(uint32_t i, uint32_t v) const
+  {
+    if (GT)
+      __hip_atomic_store(&planes[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      planes[i] = v;
+  }
+  __device__ __forceinline__ uint32_t load_count(uint32_t i) const
+  {
+    if (GT) return __hip_atomic_load(&counts[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return counts[i];
+  }
+  __device__ __forceinline__ void store_count(uint32_t i, uint32_t v) const
+  {
+    if (GT)
+      __hip_atomic_store(&counts[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      counts[i] = v;
+  }
+  __device__ __forceinline__ void store_key(uint32_t s, uint32_t v) const
+  {
+    if (GT)
+      __hip_atomic_store(&keys[s], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      keys[s] = v;
+  }
+};
+
+// tag of a pending colour: position in segment, strand, Hamming distance, library
+__device__ __forceinline__ uint32_t make_tag(uint32_t pos, uint32_t strand, uint32_t hd, uint32_t lib)
+{
+  return pos | (strand << 7) | (hd << 8) | (lib << 13);
+}
+
+struct WaveState {
+  uint2* stack;       // LDS [kStackCap]
+  uint32_t top;       // wave-uniform
+  bool overflow;      // table full for this read (any lane)
+  uint32_t err;
+};
+
+template <bool GT>
+__device__ __forceinline__ void accumulate(const Table<GT>& tb, WaveState& ws, uint32_t se, uint32_t tag)
+{
+  uint32_t key = (se << 1) | ((tag >> 7) & 1u);
+  int slot = tb.find_or_insert(key);
+  if (slot < 0) {
+    ws.overflow = true;
+    return;
+  }
+  tb.or_bit(slot, (tag >> 8) & 31u, tag & 127u);
+}
+
+// Colour expansion (the BFS of src/query.cpp:369-387, order-free here): drain the work
+// stack; tree leaves go to the accumulator, null nodes are dropped, everything else is
+// replaced by the two halves of se_to_pse[se].
+template <bool GT>
+__device__ __forceinline__ void expand_all(const DevIndex& ix, const Table<GT>& tb, WaveState& ws)
+{
+  const uint32_t lane = lane_id();
+  while (ws.top > 0) {
+    uint32_t room = kStackCap - ws.top;
+    uint32_t n = min(min(64u, ws.top), room);
+    if (n == 0) { // cannot make progress: report, drop the rest
+      ws.err |= kErrStack;
+      ws.top = 0;
+      break;
+    }
+    uint32_t base = ws.top - n;
+    bool have = lane < n;
+    uint2 item = have ? ws.stack[base + lane] : make_uint2(0, 0);
+    ws.top = base;
+    uint32_t se = item.x, tag = item.y;
+    uint32_t child[2] = {0, 0};
+    bool push[2] = {false, false};
+    if (have && se != 0) {
+      bool expand = true;
+      if (se <= ix.tree_nnodes) { // Tree::check_node (src/phytree.hpp:34)
+        uint32_t kd = ix.kind[se];
+        expand = kd == 2;
+        if (kd == 1) accumulate(tb, ws, se, tag);
+      }
+      if (expand) {
+        const DevLib& L = ix.libs[(tag >> 13) & 15u];
+        uint2 pr = se < L.nsubsets ? L.pse[se] : make_uint2(0, 0);
+        child[0] = pr.x;
+        child[1] = pr.y;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          uint32_t cs = child[c];
+          if (cs == 0) continue;
+          if (cs <= ix.tree_nnodes) {
+            uint32_t kd = ix.kind[cs];
+            if (kd == 1)
+              accumulate(tb, ws, cs, tag);
+            else if (kd == 2)
+              push[c] = true;
+          } else {
+            push[c] = true;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      uint64_t m = __ballot(push[c]);
+      if (push[c]) {
+        uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
+        ws.stack[ws.top + off] = make_uint2(child[c], tag);
+      }
+      ws.top += __popcll(m);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The probe kernel body for one read.
+// ---------------------------------------------------------------------------
+struct ProbeList {
+  uint64_t* start;   // [64]
+  uint32_t* len;     // [64]
+  uint32_t* q;       // [64]
+  uint32_t* tag;     // [64] make_tag(pos, strand, 0, lib)
+  uint32_t* pre;     // [65] exclusive prefix of 16-byte chunk counts
+};
+
+template <bool GT, bool TAP>
+__device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams& P, const BatchIn& in,
+                                             const BatchOut& out, uint32_t read, const Table<GT>& tb,
+                                             WaveState& ws, const ProbeList& pl)
+{
+  const uint32_t lane = lane_id();
+  const uint64_t off0 = in.offsets[read], off1 = in.offsets[read + 1];
+  const uint8_t* seq = in.bases + off0;
+  const uint64_t len = off1 - off0;
+  const uint32_t k = ix.k;
+  const uint64_t nkm = len >= k ? len - k + 1 : 0; // enmers (src/query.cpp:42)
+  uint32_t onmers = 0;
+  uint32_t filt[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+  ws.top = 0;
+  ws.overflow = false;
+
+  // table starts empty
+  if (!GT) {
+    for (uint32_t s = lane; s <= tb.mask; s += 64) {
+      tb.keys[s] = 0;
+      for (uint32_t x = 0; x < tb.np; ++x) {
+        tb.counts[s * tb.np + x] = 0;
+        for (int w = 0; w < kPlaneWords; ++w) tb.planes[(s * tb.np + x) * kPlaneWords + w] = 0;
+      }
+    }
+  }
+  __syncthreads();
+
+  for (uint64_t base0 = 0; base0 < nkm; base0 += kSegPos) {
+    const uint32_t npos_seg = (uint32_t)min((uint64_t)kSegPos, nkm - base0);
+    SegBits sb;
+    load_segment(seq, len, base0, sb);
+    // Four probe rounds per segment (position half pp x strand) plus a fifth, empty round
+    // whose only job is to drain the colour stack; one expand_all call site serves all.
+    FrontEnd fe;
+    fe.valid = false;
+    for (int rnd = 0; rnd < 5; ++rnd) {
+      const int pp = rnd >> 1, strand = rnd & 1;
+      uint32_t total = 0, nact = 0;
+      if (rnd < 4 && 64u * pp < npos_seg) {
+        if (strand == 0) {
+          fe = front_end(ix, sb, pp, npos_seg);
+          onmers += __popcll(__ballot(fe.valid));
+        }
+        // ---- bucket lookup for this lane's probe
+        int lib = -1;
+        uint32_t row = 0, blen = 0;
+        uint64_t bstart = 0;
+        if (fe.valid && locate_row(ix, fe.rix[strand], lib, row)) {
+          uint64_t b = ix.libs[lib].bkt[row];
+          bstart = b >> 24;
+          blen = (uint32_t)(b & 0xFFFFFFu);
+        }
+        // ---- compact non-empty probes into the LDS list, chunk counts -> prefix
+        bool act = blen > 0;
+        uint64_t am = __ballot(act);
+        nact = __popcll(am);
+        uint32_t myix = __popcll(am & ((1ull << lane) - 1ull));
+        uint32_t nchunks = act ? (uint32_t)(((bstart & 3u) + blen + 3u) >> 2) : 0u;
+        uint32_t inc = nchunks; // inclusive scan over lanes (inactive lanes add 0)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          uint32_t t = __shfl_up(inc, d);
+          if (lane >= (uint32_t)d) inc += t;
+        }
+        total = __shfl(inc, 63);
+        if (act) {
+          pl.start[myix] = bstart;
+          pl.len[myix] = blen;
+          pl.q[myix] = fe.enc32[strand];
+          pl.tag[myix] = make_tag(64u * pp + lane, (uint32_t)strand, 0, (uint32_t)lib);
+          pl.pre[myix] = inc - nchunks;
+        }
+        if (lane == 0) pl.pre[nact] = total;
+      }
+      __syncthreads();
+      // ---- scan: lanes flattened over 16-byte chunks of all listed buckets
+      for (uint32_t c0 = 0;; c0 += 64) {
+        if (rnd == 4 || ws.top > (uint32_t)(kStackCap - 256 - 64)) expand_all(ix, tb, ws);
+        if (c0 >= total) break;
+        uint32_t c = c0 + lane;
+        bool on = c < total;
+        uint32_t pi = 0;
+        if (on) { // largest pi with pre[pi] <= c
+          uint32_t lo = 0, hi = nact;
+          while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (pl.pre[mid] <= c)
+              lo = mid;
+            else
+              hi = mid;
+          }
+          pi = lo;
+        }
+        uint32_t hitmask = 0, hds = 0;
+        uint64_t e0 = 0;
+        uint32_t ptag = 0;
+        if (on) {
+          uint64_t st = pl.start[pi];
+          uint32_t ln = pl.len[pi];
+          uint32_t q = pl.q[pi];
+          ptag = pl.tag[pi];
+          uint32_t ci = c - pl.pre[pi];
+          e0 = (st & ~3ull) + 4ull * ci;
+          const DevLib& L = ix.libs[(ptag >> 13) & 15u];
+          uint4 v = *reinterpret_cast<const uint4*>(L.enc + e0);
+          uint32_t ev[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            uint64_t idx = e0 + e;
+            uint32_t hd = hd_lr32(ev[e], q);
+            bool hit = idx >= st && idx < st + ln && hd <= P.th;
+            hitmask |= hit ? (1u << e) : 0u;
+            hds |= hit ? (hd << (8 * e)) : 0u;
+          }
+        }
+        // ---- hits -> work stack (four ballot rounds, one per entry slot)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bool hit = (hitmask >> e) & 1u;
+          uint64_t hm = __ballot(hit);
+          if (hm == 0) continue;
+          if (hit) {
+            uint32_t hd = (hds >> (8 * e)) & 31u;
+            uint32_t st = (ptag >> 7) & 1u;
+            filt[st] = min(filt[st], hd);
+            uint32_t libi = (ptag >> 13) & 15u;
+            uint32_t se = ix.libs[libi].se[e0 + e];
+            uint32_t off = __popcll(hm & ((1ull << lane) - 1ull));
+            ws.stack[ws.top + off] = make_uint2(se, ptag | (hd << 8));
+            if (TAP) {
+              uint32_t hix = atomicAdd(&out.counters[3], 1u);
+              if (hix < out.hit_cap) {
+                kr_hit h;
+                h.read = read;
+                h.kpos = (uint32_t)base0 + (ptag & 127u);
+                h.strand = st;
+                h.lib = libi;
+                h.cmer_index = e0 + e;
+                h.hd = hd;
+                h.se = se;
+                out.hits[hix] = h;
+              } else {
+                atomicOr(&out.counters[1], kErrHitCap);
+              }
+            }
+          }
+          ws.top += __popcll(hm);
+        }
+        __syncthreads();
+      }
+      __syncthreads();
+    }
+    // ---- fold this segment's planes into running counts (positions of different
+    //      segments are distinct, so histograms add)
+    if (GT) {
+      __syncthreads();
+      uint32_t nt = *tb.ntouched;
+      for (uint32_t t = lane; t < nt; t += 64) {
+        uint32_t s = tb.touched[t];
+        uint32_t cum[kPlaneWords] = {0, 0, 0, 0};
+        for (uint32_t x = 0; x < tb.np; ++x) {
+          uint32_t add = 0;
+          for (int w = 0; w < kPlaneWords; ++w) {
+            uint32_t i = (s * tb.np + x) * kPlaneWords + w;
+            uint32_t pw = tb.load_plane(i);
+            add += __popc(pw & ~cum[w]);
+            cum[w] |= pw;
+            tb.store_plane(i, 0);
+          }
+          uint32_t ci = s * tb.np + x;
+          tb.store_count(ci, tb.load_count(ci) + add);
+        }
+      }
+    } else {
+      for (uint32_t s = lane; s <= tb.mask; s += 64) {
+        if (tb.keys[s] == 0) continue;
+        uint32_t cum[kPlaneWords] = {0, 0, 0, 0};
+        for (uint32_t x = 0; x < tb.np; ++x) {
+          uint32_t add = 0;
+          for (int w = 0; w < kPlaneWords; ++w) {
+            uint32_t i = (s * tb.np + x) * kPlaneWords + w;
+            uint32_t pw = tb.planes[i];
+            add += __popc(pw & ~cum[w]);
+            cum[w] |= pw;
+            tb.planes[i] = 0;
+          }
+          tb.counts[s * tb.np + x] += add;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- per-strand hdist_filt = min hd over kept table entries (src/query.cpp:366-368)
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    filt[0] = min(filt[0], (uint32_t)__shfl_xor(filt[0], d));
+    filt[1] = min(filt[1], (uint32_t)__shfl_xor(filt[1], d));
+  }
+  bool ovf = __ballot(ws.overflow) != 0;
+  if (ws.err && lane == 0) atomicOr(&out.counters[1], ws.err);
+  ws.err = 0;
+
+  if (ovf && !GT) { // redo this read with the global table
+    if (lane == 0) {
+      uint32_t o = atomicAdd(&out.counters[2], 1u);
+      out.ovf_list[o] = read;
+      out.rd_cnt[read] = 0;
+      out.rd_off[read] = 0;
+    }
+    return;
+  }
+  if (ovf && GT && lane == 0) atomicOr(&out.counters[1], kErrTable);
+
+  // ---- emit records that pass `hdist_min <= 2*hdist_filt+1` (src/query.cpp:101-106,119),
+  //      ordered by key so that the two strands of a leaf are adjacent.
+  const uint32_t lim[2] = {2u * filt[0] + 1u, 2u * filt[1] + 1u}; // u32 wrap keeps "none" = max
+  uint32_t nslots = GT ? *tb.ntouched : (tb.mask + 1);
+  uint32_t nrec = 0;
+  // pass 1: count
+  for (uint32_t t0 = 0; t0 < nslots; t0 += 64) {
+    uint32_t t = t0 + lane;
+    bool ok = false;
+    if (t < nslots) {
+      uint32_t s = GT ? tb.touched[t] : t;
+      uint32_t key = tb.load_key(s);
+      if (key) {
+        uint32_t hmin = 0xFFFFFFFFu;
+        for (uint32_t x = 0; x < tb.np; ++x)
+          if (tb.load_count(s * tb.np + x)) {
+            hmin = x;
+            break;
+          }
+        ok = hmin <= lim[key & 1u];
+      }
+    }
+    nrec += __popcll(__ballot(ok));
+  }
+  uint32_t rbase = 0;
+  if (lane == 0) {
+    rbase = atomicAdd(&out.counters[0], nrec);
+    if (rbase + nrec > out.rec_cap) {
+      atomicOr(&out.counters[1], kErrRecCap);
+      rbase = 0xFFFFFFFFu;
+    }
+    out.rd_off[read] = rbase == 0xFFFFFFFFu ? 0 : rbase;
+    out.rd_cnt[read] = rbase == 0xFFFFFFFFu ? 0 : nrec;
+    out.rd_onmers[read] = onmers;
+    out.rd_filt[2 * read] = filt[0];
+    out.rd_filt[2 * read + 1] = filt[1];
+  }
+  rbase = __shfl(rbase, 0);
+  // pass 2: rank by key and write
+  if (rbase != 0xFFFFFFFFu && nrec) {
+    for (uint32_t t0 = 0; t0 < nslots; t0 += 64) {
+      uint32_t t = t0 + lane;
+      if (t >= nslots) continue;
+      uint32_t s = GT ? tb.touched[t] : t;
+      uint32_t key = tb.load_key(s);
+      if (!key) continue;
+      uint32_t hmin = 0xFFFFFFFFu;
+      for (uint32_t x = 0; x < tb.np; ++x)
+        if (tb.load_count(s * tb.np + x)) {
+          hmin = x;
+          break;
+        }
+      if (hmin > lim[key & 1u]) continue;
+      uint32_t rank = 0;
+      for (uint32_t u = 0; u < nslots; ++u) {
+        uint32_t s2 = GT ? tb.touched[u] : u;
+        uint32_t k2 = tb.load_key(s2);
+        if (k2 == 0 || k2 >= key) continue;
+        uint32_t h2 = 0xFFFFFFFFu;
+        for (uint32_t x = 0; x < tb.np; ++x)
+          if (tb.load_count(s2 * tb.np + x)) {
+            h2 = x;
+            break;
+          }
+        rank += h2 <= lim[k2 & 1u];
+      }
+      uint32_t ri = rbase + rank;
+      out.rec_read[ri] = read;
+      out.rec_key[ri] = key;
+      for (uint32_t x = 0; x < tb.np; ++x) out.rec_hist[(uint64_t)ri * tb.np + x] = tb.load_count(s * tb.np + x);
+    }
+  }
+  // ---- global table: clear what this read touched
+  if (GT) {
+    __syncthreads();
+    uint32_t nt = *tb.ntouched;
+    for (uint32_t t = lane; t < nt; t += 64) {
+      uint32_t s = tb.touched[t];
+      tb.store_key(s, 0);
+      for (uint32_t x = 0; x < tb.np; ++x) tb.store_count(s * tb.np + x, 0);
+    }
+    __syncthreads();
+    if (lane == 0) *tb.ntouched = 0;
+    __syncthreads();
+  }
+}
+
+template <bool GT, bool TAP>
+__global__ __launch_bounds__(kWave) void kr_probe_kernel_t(DevIndex ix, DevParams P, BatchIn in, BatchOut out)
+{
+  // One carve of dynamic LDS (base is 16-byte aligned: no static __shared__ in front):
+  //   stack | probe list | ntouched | [LDS table: keys, planes, counts]
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+  uint2* s_stack = reinterpret_cast<uint2*>(s_dyn);
+  uint64_t* s_start = reinterpret_cast<uint64_t*>(s_stack + kStackCap);
+  uint32_t* s_len = reinterpret_cast<uint32_t*>(s_start + 64);
+  uint32_t* s_q = s_len + 64;
+  uint32_t* s_tag = s_q + 64;
+  uint32_t* s_pre = s_tag + 64; // 65 used, 68 reserved
+  uint32_t* s_ntouched_p = s_pre + 68;
+  uint32_t* s_tbl = s_ntouched_p + 4;
+#define s_ntouched (*s_ntouched_p)
+
+  Table<GT> tb;
+  tb.np = P.np;
+  tb.ntouched = s_ntouched_p;
+  if (GT) {
+    uint64_t w = blockIdx.x;
+    tb.keys = out.g_keys + w * out.g_slots;
+    tb.planes = out.g_planes + w * (uint64_t)out.g_slots * P.np * kPlaneWords;
+    tb.counts = out.g_counts + w * (uint64_t)out.g_slots * P.np;
+    tb.touched = out.g_touched + w * out.g_slots;
+    tb.mask = out.g_slots - 1;
+  } else {
+    tb.keys = s_tbl;
+    tb.planes = s_tbl + kLdsSlots;
+    tb.counts = tb.planes + kLdsSlots * P.np * kPlaneWords;
+    tb.touched = nullptr;
+    tb.mask = kLdsSlots - 1;
+  }
+  if (threadIdx.x == 0) s_ntouched = 0;
+  __syncthreads();
+  WaveState ws;
+  ws.stack = s_stack;
+  ws.top = 0;
+  ws.overflow = false;
+  ws.err = 0;
+  ProbeList pl{s_start, s_len, s_q, s_tag, s_pre};
+#undef s_ntouched
+
+  if (GT) {
+    uint32_t n = out.counters[2];
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x)
+      process_read<GT, TAP>(ix, P, in, out, out.ovf_list[i], tb, ws, pl);
+  } else {
+    for (uint32_t r = blockIdx.x; r < in.nreads; r += gridDim.x) process_read<GT, TAP>(ix, P, in, out, r, tb, ws, pl);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Likelihood (HDistHistLLH::operator(), src/hdhistllh.hpp:71-89) and Brent
+// ---------------------------------------------------------------------------
+struct LlhProblem {
+  double mc[kMaxPlanes];
+  double uc, rho;
+};
+
+__device__ double llh_eval(const LlhConst& C, const LlhProblem& p, double d)
+{
+  double sum = 0.0, lv_m = 0.0;
+  double powdc = pow(1.0 - d, (double)C.k);
+  double logdn = log(1.0 - d);
+  double logdp = log(d) - logdn;
+  logdn *= (double)C.k;
+  double dratio = d / (1.0 - d);
+  for (uint32_t x = 0; x <= C.k; ++x) {
+    if (x <= C.th) {
+      sum -= (logdn + (double)x * logdp) * p.mc[x];
+      lv_m += C.binom_hnk[x] * powdc;
+    } else {
+      lv_m += powdc * C.binom_k[x];
+    }
+    powdc *= dratio;
+  }
+  return sum - log(p.rho * lv_m + 1.0 - p.rho) * p.uc;
+}
+
+// boost::math::tools::brent_find_minima(f, 1e-10, 0.5, 16) (src/query.cpp:430);
+// published algorithm, see SURVEY.md Appendix B.
+__device__ void brent_min(const LlhConst& C, const LlhProblem& p, double& d_out, double& v_out)
+{
+  double mn = 1e-10, mx = 0.5;
+  const double tolerance = 0x1p-15; // ldexp(1, 1 - min(53/2, 16))
+  const double golden = 0.3819660f;
+  double x, w, v, u, delta, delta2, fu, fv, fw, fx, mid, fract1, fract2;
+  x = w = v = mx;
+  fw = fv = fx = llh_eval(C, p, x);
+  delta2 = delta = 0;
+  for (int it = 0; it < 1000; ++it) {
+    mid = (mn + mx) / 2;
+    fract1 = tolerance * fabs(x) + tolerance / 4;
+    fract2 = 2 * fract1;
+    if (fabs(x - mid) <= (fract2 - (mx - mn) / 2)) break;
+    if (fabs(delta2) > fract1) {
+      double r = (x - w) * (fx - fv);
+      double q = (x - v) * (fx - fw);
+      double pp = (x - v) * q - (x - w) * r;
+      q = 2 * (q - r);
+      if (q > 0) pp = -pp;
+      q = fabs(q);
+      double td = delta2;
+      delta2 = delta;
+      if ((fabs(pp) >= fabs(q * td / 2)) || (pp <= q * (mn - x)) || (pp >= q * (mx - x))) {
+        delta2 = (x >= mid) ? mn - x : mx - x;
+        delta = golden * delta2;
+      } else {
+        delta = pp / q;
+        u = x + delta;
+        if (((u - mn) < fract2) || ((mx - u) < fract2)) delta = (mid - x) < 0 ? -fabs(fract1) : fabs(fract1);
+      }
+    } else {
+      delta2 = (x >= mid) ? mn - x : mx - x;
+      delta = golden * delta2;
+    }
+    u = (fabs(delta) >= fract1) ? (x + delta) : (delta > 0 ? (x + fabs(fract1)) : (x - fabs(fract1)));
+    fu = llh_eval(C, p, u);
+    if (fu <= fx) {
+      if (u >= x)
+        mn = x;
+      else
+        mx = x;
+      v = w, w = x, x = u;
+      fv = fw, fw = fx, fx = fu;
+    } else {
+      if (u < x)
+        mn = u;
+      else
+        mx = u;
+      if ((fu <= fw) || (w == x)) {
+        v = w, w = u;
+        fv = fw, fw = fu;
+      } else if ((fu <= fv) || (v == x) || (v == w)) {
+        v = u;
+        fv = fu;
+      }
+    }
+  }
+  d_out = x;
+  v_out = fx;
+}
+
+__device__ __forceinline__ void load_problem(const LlhConst& C, const uint32_t* hist, uint32_t onmers, double rho,
+                                             LlhProblem& p)
+{
+  uint32_t mc = 0;
+  for (uint32_t x = 0; x <= C.th; ++x) {
+    p.mc[x] = (double)hist[x];
+    mc += hist[x];
+  }
+  p.uc = (double)onmers - (double)mc; // mismatch_count = onmers - match_count (src/query.cpp:104)
+  p.rho = rho;
+}
+
+__global__ __launch_bounds__(256) void kr_llh_kernel(LlhConst C, DevIndex ix, BatchOut out)
+{
+  uint32_t nrec = min(out.counters[0], out.rec_cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += gridDim.x * blockDim.x) {
+    uint32_t key = out.rec_key[i];
+    uint32_t read = out.rec_read[i];
+    LlhProblem p;
+    load_problem(C, out.rec_hist + (uint64_t)i * (C.th + 1), out.rd_onmers[read], ix.libs[0].rho[key >> 1], p);
+    double d, v;
+    brent_min(C, p, d, v);
+    out.rec_d[i] = d;
+    out.rec_v[i] = v;
+  }
+}
+
+// summarize_matches' strand merge and closest (src/query.cpp:96-139) + the row selection
+// of report_distances (src/query.cpp:158-196).  Records of a read are sorted by
+// key = (se << 1) | strand.  Iteration order of the reference's maps is arbitrary; the
+// order used here (all forward leaves by ascending se, then all reverse ones) is the
+// oracle's, so `<=` ties resolve identically.
+__global__ __launch_bounds__(256) void kr_select_kernel(LlhConst C, DevIndex ix, DevParams P, BatchOut out,
+                                                        uint32_t nreads)
+{
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += gridDim.x * blockDim.x) {
+    uint32_t o = out.rd_off[r], n = out.rd_cnt[r];
+    // closest: last record in (strand, se) order with d <= best
+    double best = 1.7976931348623157e308;
+    int cl = -1;
+    for (int strand = 0; strand < 2; ++strand)
+      for (uint32_t i = o; i < o + n; ++i)
+        if ((out.rec_key[i] & 1u) == (uint32_t)strand && out.rec_d[i] <= best) {
+          best = out.rec_d[i];
+          cl = (int)i;
+        }
+    bool na = (n == 0) || (P.dmax_set && best > P.dist_max);
+    out.rd_na[r] = na ? 1 : 0;
+    LlhProblem pc;
+    double vcl = 0;
+    if (cl >= 0 && !P.no_filter) {
+      load_problem(C, out.rec_hist + (uint64_t)cl * (C.th + 1), out.rd_onmers[r], ix.libs[0].rho[out.rec_key[cl] >> 1],
+                   pc);
+      vcl = out.rec_v[cl];
+    }
+    for (uint32_t i = o; i < o + n; ++i) {
+      uint32_t key = out.rec_key[i];
+      // which record represents this leaf in node_to_minfo?
+      bool chosen;
+      bool has_other = (key & 1u) ? (i > o && out.rec_key[i - 1] == (key ^ 1u)) : (i + 1 < o + n && out.rec_key[i + 1] == (key ^ 1u));
+      if (!has_other) {
+        chosen = true;
+      } else {
+        uint32_t io = (key & 1u) ? i - 1 : i, ir = (key & 1u) ? i : i + 1;
+        double d_or = out.rec_d[io], d_rc = out.rec_d[ir];
+        uint32_t m_or = 0, m_rc = 0;
+        for (uint32_t x = 0; x <= C.th; ++x) {
+          m_or += out.rec_hist[(uint64_t)io * (C.th + 1) + x];
+          m_rc += out.rec_hist[(uint64_t)ir * (C.th + 1) + x];
+        }
+        bool take_or = (d_rc > d_or) || ((d_rc == d_or) && (m_rc < m_or)); // src/query.cpp:129-133
+        // the closest overrides (src/query.cpp:136-138)
+        if (cl >= 0 && (out.rec_key[cl] >> 1) == (key >> 1)) take_or = ((uint32_t)cl == io);
+        chosen = (key & 1u) ? !take_or : take_or;
+      }
+      double d = out.rec_d[i];
+      double chi = nan("");
+      bool sel = false;
+      if (chosen && !na) {
+        bool dm = !P.dmax_set || d < P.dist_max;
+        if (!P.multi) {
+          sel = (int)i == cl;
+        } else if (P.no_filter) {
+          sel = dm;
+        } else {
+          chi = 2 * (llh_eval(C, pc, d) - vcl); // Minfo::likelihood_ratio (src/query.cpp:420-424)
+          sel = (chi < P.chisq) && dm;
+        }
+      }
+      out.rec_sel[i] = sel ? 1 : 0;
+      out.rec_chisq[i] = chi;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Debug kernels
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void kr_front_end_kernel(DevIndex ix, BatchIn in, uint32_t stride, uint32_t* rix,
+                                                            uint32_t* enc32, uint8_t* valid, uint8_t* pass)
+{
+  const uint32_t lane = lane_id();
+  for (uint32_t r = blockIdx.x; r < in.nreads; r += gridDim.x) {
+    const uint64_t off0 = in.offsets[r], len = in.offsets[r + 1] - off0;
+    const uint8_t* seq = in.bases + off0;
+    const uint64_t nkm = len >= ix.k ? len - ix.k + 1 : 0;
+    for (uint64_t base0 = 0; base0 < nkm; base0 += kSegPos) {
+      const uint32_t npos_seg = (uint32_t)min((uint64_t)kSegPos, nkm - base0);
+      SegBits sb;
+      load_segment(seq, len, base0, sb);
+      for (int pp = 0; pp < 2; ++pp) {
+        FrontEnd fe = front_end(ix, sb, pp, npos_seg);
+        uint64_t j = base0 + 64u * pp + lane;
+        if (64u * pp + lane < npos_seg && j < stride) {
+          for (int s = 0; s < 2; ++s) {
+            uint64_t o = ((uint64_t)r * stride + j) * 2 + s;
+            int lib;
+            uint32_t row;
+            rix[o] = fe.rix[s];
+            enc32[o] = fe.enc32[s];
+            valid[o] = fe.valid;
+            pass[o] = fe.valid && locate_row(ix, fe.rix[s], lib, row);
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ void kr_brent_kernel(LlhConst C, uint32_t n, const uint32_t* hist, const uint32_t* onmers, const double* rho,
+                                double* d_out, double* v_out)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  LlhProblem p;
+  load_problem(C, hist + (uint64_t)i * (C.th + 1), onmers[i], rho[i], p);
+  brent_min(C, p, d_out[i], v_out[i]);
+}
+
+// Re-layout kernels used by kr_index_upload.
+__global__ void kr_relayout_cmer(const uint32_t* cmer, uint64_t n, uint32_t* enc, uint32_t* se)
+{
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint2 v = reinterpret_cast<const uint2*>(cmer)[i];
+    enc[i] = v.x;
+    se[i] = v.y;
+  }
+}
+__global__ void kr_relayout_inc(const uint64_t* inc, uint32_t nrows, uint64_t* bkt, uint32_t* bad)
+{
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += gridDim.x * blockDim.x) {
+    uint64_t e = inc[i], s = i ? inc[i - 1] : 0; // FlatHT::bucket_start/next (src/table.hpp:121-136)
+    uint64_t l = e >= s ? e - s : 0;
+    if (e < s || l > 0xFFFFFFull || s >= (1ull << 40)) atomicOr(bad, 1u);
+    bkt[i] = (s << 24) | (l & 0xFFFFFFull);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Host side of the device ABI
+// ---------------------------------------------------------------------------
+#define HIP_TRY(expr)                                                                                       \
+  do {                                                                                                      \
+    hipError_t e__ = (expr);                                                                                \
+    if (e__ != hipSuccess)                                                                                  \
+      return kr::fail(e__ == hipErrorOutOfMemory ? KR_ERR_NOMEM : KR_ERR_NO_DEVICE,                          \
+                      std::string(#expr) + ": " + hipGetErrorString(e__));                                  \
+  } while (0)
+
+// dynamic LDS bytes of the probe kernel: stack + probe list + ntouched (+ table)
+uint32_t probe_lds_bytes(bool global_table, uint32_t np)
+{
+  uint32_t b = kStackCap * 8 + 64 * 8 + 3 * 64 * 4 + 68 * 4 + 16;
+  if (!global_table) b += kLdsSlots * 4 + kLdsSlots * np * kPlaneWords * 4 + kLdsSlots * np * 4;
+  return (b + 15u) & ~15u;
+}
+
+Runs make_runs(const std::vector<uint8_t>& asc)
+{
+  Runs r;
+  memset(&r, 0, sizeof(r));
+  size_t i = 0;
+  while (i < asc.size()) {
+    size_t j = i + 1;
+    while (j < asc.size() && asc[j] == asc[j - 1] + 1) ++j;
+    r.src[r.n] = asc[i];
+    r.len[r.n] = (uint8_t)(j - i);
+    r.dst[r.n] = (uint8_t)i;
+    r.n++;
+    i = j;
+  }
+  return r;
+}
+
+LlhConst make_llh_const(uint32_t k, uint32_t h, uint32_t th)
+{ // HDistHistLLH ctor (src/hdhistllh.hpp:51-69): uint64 arithmetic, then exact conversion
+  LlhConst C;
+  memset(&C, 0, sizeof(C));
+  C.k = k, C.h = h, C.th = th;
+  uint64_t bk[32] = {0};
+  bk[0] = 1;
+  for (uint32_t i = 0; i < k; ++i) bk[i + 1] = (bk[i] * (k - i)) / (i + 1);
+  for (uint32_t i = 0; i <= k; ++i) C.binom_k[i] = (double)bk[i];
+  uint64_t vc = 1, nh = k - h;
+  C.binom_hnk[0] = 0.0;
+  for (uint32_t i = 1; i <= th; ++i) {
+    vc = (vc * (nh - i + 1)) / i;
+    C.binom_hnk[i] = (double)(bk[i] - vc);
+  }
+  return C;
+}
+
+} // namespace
+
+struct kr_index {
+  int device = 0;
+  DevIndex dix;
+  std::vector<DevLib> hlibs;    // host copy of the device DevLib array
+  std::vector<void*> allocs;    // everything to hipFree
+  std::vector<kr_index_buffer> bufs; // export order
+  std::vector<uint8_t> desc;    // export descriptor
+  uint64_t bytes = 0;
+};
+
+namespace {
+
+struct DescHeader {
+  uint32_t magic, k, h, m, nlibs, tree_nnodes;
+  uint8_t ppos[32], npos[32];
+};
+struct DescLib {
+  uint64_t nkmers;
+  uint32_t nrows, nsubsets, nnodes, numer;
+};
+
+int dev_alloc(kr_index* ix, void** p, uint64_t bytes)
+{
+  HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+  ix->allocs.push_back(*p);
+  ix->bytes += bytes;
+  return KR_OK;
+}
+
+// Allocate every device buffer of an index from its descriptor; fills ix->dix/hlibs/bufs.
+int alloc_from_desc(kr_index* ix, const DescHeader& H, const std::vector<DescLib>& L)
+{
+  ix->hlibs.resize(H.nlibs);
+  ix->bufs.clear();
+  for (uint32_t i = 0; i < H.nlibs; ++i) {
+    DevLib& d = ix->hlibs[i];
+    memset(&d, 0, sizeof(d));
+    d.nkmers = L[i].nkmers, d.nrows = L[i].nrows, d.nsubsets = L[i].nsubsets, d.nnodes = L[i].nnodes,
+    d.numer = L[i].numer;
+    void* p;
+    int rc;
+    uint64_t b;
+    b = (uint64_t)d.nrows * 8;
+    if ((rc = dev_alloc(ix, &p, b))) return rc;
+    d.bkt = (const uint64_t*)p;
+    ix->bufs.push_back({p, b});
+    b = (d.nkmers + 16) * 4; // 16 entries of slack: 16-byte chunk loads may run past the end
+    if ((rc = dev_alloc(ix, &p, b))) return rc;
+    d.enc = (const uint32_t*)p;
+    ix->bufs.push_back({p, b});
+    b = (d.nkmers + 16) * 4;
+    if ((rc = dev_alloc(ix, &p, b))) return rc;
+    d.se = (const uint32_t*)p;
+    ix->bufs.push_back({p, b});
+    b = (uint64_t)d.nsubsets * 8;
+    if ((rc = dev_alloc(ix, &p, b))) return rc;
+    d.pse = (const uint2*)p;
+    ix->bufs.push_back({p, b});
+    b = (uint64_t)d.nnodes * 8;
+    if ((rc = dev_alloc(ix, &p, b))) return rc;
+    d.rho = (const double*)p;
+    ix->bufs.push_back({p, b});
+  }
+  void* p;
+  int rc;
+  uint64_t b = (uint64_t)H.tree_nnodes + 1;
+  if ((rc = dev_alloc(ix, &p, b))) return rc;
+  ix->dix.kind = (const uint8_t*)p;
+  ix->bufs.push_back({p, b});
+  b = (uint64_t)H.m * 4;
+  if ((rc = dev_alloc(ix, &p, b))) return rc;
+  ix->dix.res_lib = (const int32_t*)p;
+  ix->bufs.push_back({p, b});
+  b = (uint64_t)H.nlibs * sizeof(DevLib);
+  if ((rc = dev_alloc(ix, &p, b))) return rc;
+  ix->dix.libs = (const DevLib*)p;
+  HIP_TRY(hipMemcpy(p, ix->hlibs.data(), b, hipMemcpyHostToDevice)); // pointers are per-device: never exported
+
+  ix->dix.k = H.k, ix->dix.h = H.h, ix->dix.m = H.m, ix->dix.nlibs = H.nlibs, ix->dix.tree_nnodes = H.tree_nnodes;
+  ix->dix.m_shift = 0xFFFFFFFFu;
+  if ((H.m & (H.m - 1)) == 0) {
+    uint32_t s = 0;
+    while ((1u << s) < H.m) ++s;
+    ix->dix.m_shift = s;
+  }
+  std::vector<uint8_t> pasc(H.ppos, H.ppos + H.h), nasc(H.npos, H.npos + (H.k - H.h));
+  std::sort(pasc.begin(), pasc.end());
+  std::sort(nasc.begin(), nasc.end());
+  ix->dix.prun = make_runs(pasc);
+  ix->dix.nrun = make_runs(nasc);
+  ix->desc.resize(sizeof(DescHeader) + L.size() * sizeof(DescLib));
+  memcpy(ix->desc.data(), &H, sizeof(H));
+  memcpy(ix->desc.data() + sizeof(H), L.data(), L.size() * sizeof(DescLib));
+  return KR_OK;
+}
+
+constexpr uint32_t kDescMagic = 0x4b524958u; // "KRIX"
+
+} // namespace
+
+extern "C" {
+
+int kr_index_upload(const kr_index_view* v, int device, uint32_t flags, kr_index** out)
+{
+  kr::clear_error();
+  if (!v || !out || !v->libs || !v->ppos || !v->npos || !v->node_kind) return kr::fail(KR_ERR_ARG, "kr_index_upload: null argument");
+  *out = nullptr;
+  if (v->k < 3 || v->k > 31 || v->h == 0 || v->h >= v->k || v->k - v->h > 16 || v->h > 15)
+    return kr::fail(KR_ERR_ARG, "kr_index_upload: unsupported k/h (need k<=31, k-h<=16, h<=15)");
+  if (v->nlibs == 0 || v->nlibs > (uint32_t)kMaxLibs) return kr::fail(KR_ERR_ARG, "kr_index_upload: 1..16 partial libraries supported");
+  if (v->m == 0 || v->m > 65536) return kr::fail(KR_ERR_ARG, "kr_index_upload: m out of range");
+  if (v->tree_nnodes >= (1u << 30)) return kr::fail(KR_ERR_ARG, "kr_index_upload: tree too large");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return kr::fail(KR_ERR_NO_DEVICE, "no HIP device available");
+  if (device < 0 || device >= ndev) return kr::fail(KR_ERR_ARG, "kr_index_upload: bad device ordinal");
+  HIP_TRY(hipSetDevice(device));
+
+  DescHeader H;
+  memset(&H, 0, sizeof(H));
+  H.magic = kDescMagic, H.k = v->k, H.h = v->h, H.m = v->m, H.nlibs = v->nlibs, H.tree_nnodes = v->tree_nnodes;
+  memcpy(H.ppos, v->ppos, v->h);
+  memcpy(H.npos, v->npos, v->k - v->h);
+  std::vector<DescLib> L(v->nlibs);
+  std::vector<int32_t> res_lib(v->m, -1);
+  for (uint32_t i = 0; i < v->nlibs; ++i) {
+    const kr_lib_view& lv = v->libs[i];
+    if (lv.r >= v->m) return kr::fail(KR_ERR_FORMAT, "library residue r >= m");
+    if (lv.nnodes != v->tree_nnodes + 1) return kr::fail(KR_ERR_FORMAT, "crecord nnodes does not match the tree");
+    L[i] = DescLib{lv.nkmers, lv.nrows, lv.nsubsets, lv.nnodes, lv.frac ? lv.r + 1 : 1u};
+    // src/index.cpp:144-157
+    if (lv.frac)
+      for (uint32_t q = 0; q <= lv.r; ++q) res_lib[q] = (int32_t)i;
+    else
+      res_lib[lv.r] = (int32_t)i;
+  }
+  std::unique_ptr<kr_index> ix(new kr_index());
+  ix->device = device;
+  int rc = alloc_from_desc(ix.get(), H, L);
+  if (rc) {
+    kr_index_free(ix.release());
+    return rc;
+  }
+  const hipMemcpyKind kind = (flags & KR_VIEW_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  uint32_t* d_bad = nullptr;
+  HIP_TRY(hipMalloc(&d_bad, 4));
+  HIP_TRY(hipMemset(d_bad, 0, 4));
+  for (uint32_t i = 0; i < v->nlibs; ++i) {
+    const kr_lib_view& lv = v->libs[i];
+    const DevLib& d = ix->hlibs[i];
+    // stage the on-disk arrays, then re-lay them out on the device
+    const uint32_t* src_cmer = lv.cmer;
+    const uint64_t* src_inc = lv.inc;
+    void *t_cmer = nullptr, *t_inc = nullptr;
+    if (!(flags & KR_VIEW_DEVICE)) {
+      HIP_TRY(hipMalloc(&t_cmer, lv.nkmers * 8 + 16));
+      HIP_TRY(hipMemcpy(t_cmer, lv.cmer, lv.nkmers * 8, hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&t_inc, (uint64_t)lv.nrows * 8 + 16));
+      HIP_TRY(hipMemcpy(t_inc, lv.inc, (uint64_t)lv.nrows * 8, hipMemcpyHostToDevice));
+      src_cmer = (const uint32_t*)t_cmer;
+      src_inc = (const uint64_t*)t_inc;
+    }
+    HIP_TRY(hipMemset((void*)d.enc, 0xFF, (d.nkmers + 16) * 4));
+    HIP_TRY(hipMemset((void*)d.se, 0, (d.nkmers + 16) * 4));
+    if (lv.nkmers) hipLaunchKernelGGL(kr_relayout_cmer, dim3(2048), dim3(256), 0, 0, src_cmer, lv.nkmers, (uint32_t*)d.enc, (uint32_t*)d.se);
+    if (lv.nrows) hipLaunchKernelGGL(kr_relayout_inc, dim3(1024), dim3(256), 0, 0, src_inc, lv.nrows, (uint64_t*)d.bkt, d_bad);
+    HIP_TRY(hipDeviceSynchronize());
+    if (t_cmer) hipFree(t_cmer);
+    if (t_inc) hipFree(t_inc);
+    HIP_TRY(hipMemcpy((void*)d.pse, lv.pse, (uint64_t)lv.nsubsets * 8, kind));
+    HIP_TRY(hipMemcpy((void*)d.rho, lv.rho, (uint64_t)lv.nnodes * 8, kind));
+  }
+  uint32_t bad = 0;
+  HIP_TRY(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
+  hipFree(d_bad);
+  if (bad) {
+    kr_index_free(ix.release());
+    return kr::fail(KR_ERR_FORMAT, "inc-* is not monotone or a bucket exceeds 2^24 entries / 2^40 offset");
+  }
+  HIP_TRY(hipMemcpy((void*)ix->dix.kind, v->node_kind, (uint64_t)v->tree_nnodes + 1, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy((void*)ix->dix.res_lib, res_lib.data(), (uint64_t)v->m * 4, hipMemcpyHostToDevice));
+  *out = ix.release();
+  return KR_OK;
+}
+
+void kr_index_free(kr_index* ix)
+{
+  if (!ix) return;
+  (void)hipSetDevice(ix->device);
+  for (void* p : ix->allocs) (void)hipFree(p);
+  delete ix;
+}
+
+uint64_t kr_index_device_bytes(const kr_index* ix) { return ix ? ix->bytes : 0; }
+
+int kr_index_export(const kr_index* ix, void* desc, uint64_t* desc_bytes, kr_index_buffer* bufs, uint32_t* nbufs)
+{
+  if (!ix || !desc_bytes || !nbufs) return kr::fail(KR_ERR_ARG, "kr_index_export: null argument");
+  uint64_t need = ix->desc.size();
+  uint32_t nb = (uint32_t)ix->bufs.size();
+  bool fits = desc && *desc_bytes >= need && bufs && *nbufs >= nb;
+  *desc_bytes = need;
+  *nbufs = nb;
+  if (!fits) return (desc || bufs) ? kr::fail(KR_ERR_ARG, "kr_index_export: buffers too small") : KR_OK;
+  memcpy(desc, ix->desc.data(), need);
+  memcpy(bufs, ix->bufs.data(), nb * sizeof(kr_index_buffer));
+  return KR_OK;
+}
+
+int kr_index_import(const void* desc, uint64_t desc_bytes, int device, kr_index** out, kr_index_buffer* bufs, uint32_t* nbufs)
+{
+  kr::clear_error();
+  if (!desc || !out || !nbufs || desc_bytes < sizeof(DescHeader)) return kr::fail(KR_ERR_ARG, "kr_index_import: bad argument");
+  DescHeader H;
+  memcpy(&H, desc, sizeof(H));
+  if (H.magic != kDescMagic || desc_bytes != sizeof(H) + (uint64_t)H.nlibs * sizeof(DescLib) || H.nlibs == 0 || H.nlibs > (uint32_t)kMaxLibs)
+    return kr::fail(KR_ERR_FORMAT, "kr_index_import: bad descriptor");
+  std::vector<DescLib> L(H.nlibs);
+  memcpy(L.data(), (const uint8_t*)desc + sizeof(H), H.nlibs * sizeof(DescLib));
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return kr::fail(KR_ERR_NO_DEVICE, "no HIP device available");
+  if (device < 0 || device >= ndev) return kr::fail(KR_ERR_ARG, "kr_index_import: bad device ordinal");
+  HIP_TRY(hipSetDevice(device));
+  std::unique_ptr<kr_index> ix(new kr_index());
+  ix->device = device;
+  int rc = alloc_from_desc(ix.get(), H, L);
+  if (rc) {
+    kr_index_free(ix.release());
+    return rc;
+  }
+  uint32_t nb = (uint32_t)ix->bufs.size();
+  if (!bufs || *nbufs < nb) {
+    *nbufs = nb;
+    kr_index_free(ix.release());
+    return kr::fail(KR_ERR_ARG, "kr_index_import: bufs too small");
+  }
+  memcpy(bufs, ix->bufs.data(), nb * sizeof(kr_index_buffer));
+  *nbufs = nb;
+  *out = ix.release();
+  return KR_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// kr_stream
+// ---------------------------------------------------------------------------
+struct kr_stream {
+  const kr_index* ix = nullptr;
+  kr_params params;
+  DevParams dp;
+  LlhConst llh;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t max_reads = 0;
+  uint64_t max_bases = 0;
+  uint32_t rec_cap = 0, hit_cap = 0;
+  uint32_t nwaves = 0, ovf_waves = 0;
+  // device
+  uint8_t* d_bases = nullptr;
+  uint64_t* d_offsets = nullptr;
+  BatchOut out;
+  std::vector<void*> dallocs;
+  // pinned host
+  uint8_t* h_bases = nullptr;
+  uint64_t* h_offsets = nullptr;
+  uint32_t* h_counters = nullptr;
+  uint32_t *h_rd_off = nullptr, *h_rd_cnt = nullptr, *h_rd_onmers = nullptr, *h_rd_filt = nullptr;
+  uint8_t* h_rd_na = nullptr;
+  uint32_t *h_rec_key = nullptr, *h_rec_hist = nullptr;
+  uint8_t* h_rec_sel = nullptr;
+  double *h_rec_d = nullptr, *h_rec_v = nullptr, *h_rec_chisq = nullptr;
+  kr_hit* h_hits = nullptr;
+  std::vector<void*> hallocs;
+  // state
+  bool submitted = false, waited = false;
+  uint32_t nreads = 0, flags = 0, nrecs = 0;
+  uint64_t nhits = 0;
+  BatchIn in;
+};
+
+namespace {
+
+template <typename T>
+int salloc(kr_stream* s, T** p, uint64_t n)
+{
+  HIP_TRY(hipMalloc((void**)p, std::max<uint64_t>(16, n * sizeof(T))));
+  s->dallocs.push_back(*p);
+  return KR_OK;
+}
+template <typename T>
+int halloc(kr_stream* s, T** p, uint64_t n)
+{
+  HIP_TRY(hipHostMalloc((void**)p, std::max<uint64_t>(16, n * sizeof(T)), hipHostMallocDefault));
+  s->hallocs.push_back(*p);
+  return KR_OK;
+}
+
+uint32_t next_pow2(uint32_t v)
+{
+  uint32_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+int check_errflags(uint32_t e)
+{
+  if (e & kErrRecCap) return kr::fail(KR_ERR_CAPACITY, "record buffer overflow: submit fewer reads per batch");
+  if (e & kErrStack) return kr::fail(KR_ERR_CAPACITY, "colour work stack overflow (colour DAG deeper than supported)");
+  if (e & kErrTable) return kr::fail(KR_ERR_CAPACITY, "global accumulator table overflow");
+  if (e & kErrHitCap) return kr::fail(KR_ERR_CAPACITY, "hit tap buffer overflow");
+  return KR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads, uint64_t max_bases, kr_stream** out)
+{
+  kr::clear_error();
+  if (!ix || !p || !out || max_reads == 0) return kr::fail(KR_ERR_ARG, "kr_stream_create: bad argument");
+  if (p->hdist_th > KR_MAX_HDIST_TH) return kr::fail(KR_ERR_ARG, "--hdist-th above 16 is not supported (k-h <= 16 bounds hd)");
+  HIP_TRY(hipSetDevice(ix->device));
+  std::unique_ptr<kr_stream> s(new kr_stream());
+  s->ix = ix;
+  s->params = *p;
+  s->dp.th = p->hdist_th, s->dp.np = p->hdist_th + 1;
+  s->dp.multi = p->multi, s->dp.no_filter = p->no_filter;
+  s->dp.dmax_set = std::isnan(p->dist_max) ? 0 : 1;
+  s->dp.chisq = p->chisq, s->dp.dist_max = p->dist_max;
+  s->llh = make_llh_const(ix->dix.k, ix->dix.h, p->hdist_th);
+  s->max_reads = max_reads, s->max_bases = max_bases;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
+  s->nwaves = (uint32_t)prop.multiProcessorCount * 12u;
+  s->ovf_waves = (uint32_t)prop.multiProcessorCount * 2u;
+  uint32_t nleaves2 = 2u * (ix->dix.tree_nnodes + 1);
+  uint32_t g_slots = std::min<uint32_t>(next_pow2(std::max<uint32_t>(256u, 2u * nleaves2)), 1u << 16);
+  uint64_t per_read = std::min<uint64_t>(64, std::max<uint64_t>(8, (uint64_t)ix->dix.tree_nnodes + 1)); // <= 2 * leaves
+  uint64_t rc64 = std::max<uint64_t>(1u << 16, (uint64_t)max_reads * per_read);
+  s->rec_cap = (uint32_t)std::min<uint64_t>(rc64, 1ull << 30);
+  s->hit_cap = 1u << 22;
+  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
+  int rc = 0;
+  BatchOut& o = s->out;
+  memset(&o, 0, sizeof(o));
+  uint32_t np = s->dp.np;
+#define SA(ptr, n) \
+  if ((rc = salloc(s.get(), &ptr, (n)))) { kr_stream_destroy(s.release()); return rc; }
+#define HA(ptr, n) \
+  if ((rc = halloc(s.get(), &ptr, (n)))) { kr_stream_destroy(s.release()); return rc; }
+  SA(s->d_bases, max_bases + 256);
+  SA(s->d_offsets, (uint64_t)max_reads + 1);
+  SA(o.counters, 8);
+  SA(o.rd_off, max_reads);
+  SA(o.rd_cnt, max_reads);
+  SA(o.rd_onmers, max_reads);
+  SA(o.rd_filt, 2ull * max_reads);
+  SA(o.rd_na, max_reads);
+  SA(o.rec_read, s->rec_cap);
+  SA(o.rec_key, s->rec_cap);
+  SA(o.rec_hist, (uint64_t)s->rec_cap * np);
+  SA(o.rec_d, s->rec_cap);
+  SA(o.rec_v, s->rec_cap);
+  SA(o.rec_chisq, s->rec_cap);
+  SA(o.rec_sel, s->rec_cap);
+  SA(o.ovf_list, max_reads);
+  o.rec_cap = s->rec_cap;
+  o.hit_cap = s->hit_cap;
+  o.g_slots = g_slots;
+  SA(o.g_keys, (uint64_t)s->ovf_waves * g_slots);
+  SA(o.g_planes, (uint64_t)s->ovf_waves * g_slots * np * kPlaneWords);
+  SA(o.g_counts, (uint64_t)s->ovf_waves * g_slots * np);
+  SA(o.g_touched, (uint64_t)s->ovf_waves * g_slots);
+  HIP_TRY(hipMemset(o.g_keys, 0, (uint64_t)s->ovf_waves * g_slots * 4));
+  HIP_TRY(hipMemset(o.g_planes, 0, (uint64_t)s->ovf_waves * g_slots * np * kPlaneWords * 4));
+  HIP_TRY(hipMemset(o.g_counts, 0, (uint64_t)s->ovf_waves * g_slots * np * 4));
+  HA(s->h_bases, max_bases + 256);
+  HA(s->h_offsets, (uint64_t)max_reads + 1);
+  HA(s->h_counters, 8);
+  HA(s->h_rd_off, max_reads);
+  HA(s->h_rd_cnt, max_reads);
+  HA(s->h_rd_onmers, max_reads);
+  HA(s->h_rd_filt, 2ull * max_reads);
+  HA(s->h_rd_na, max_reads);
+  HA(s->h_rec_key, s->rec_cap);
+  HA(s->h_rec_hist, (uint64_t)s->rec_cap * np);
+  HA(s->h_rec_sel, s->rec_cap);
+  HA(s->h_rec_d, s->rec_cap);
+  HA(s->h_rec_v, s->rec_cap);
+  HA(s->h_rec_chisq, s->rec_cap);
+#undef SA
+#undef HA
+  *out = s.release();
+  return KR_OK;
+}
+
+void kr_stream_destroy(kr_stream* s)
+{
+  if (!s) return;
+  if (s->ix) (void)hipSetDevice(s->ix->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  for (void* p : s->dallocs) (void)hipFree(p);
+  for (void* p : s->hallocs) (void)hipHostFree(p);
+  for (auto& e : s->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads, uint32_t flags)
+{
+  kr::clear_error();
+  if (!s || !bases || !offsets) return kr::fail(KR_ERR_ARG, "kr_batch_submit: null argument");
+  if (nreads == 0 || nreads > s->max_reads) return kr::fail(KR_ERR_ARG, "kr_batch_submit: nreads out of range for this stream");
+  HIP_TRY(hipSetDevice(s->ix->device));
+  if (s->submitted && !s->waited) HIP_TRY(hipStreamSynchronize(s->stream));
+  s->nreads = nreads;
+  s->flags = flags;
+  s->submitted = true;
+  s->waited = false;
+  hipStream_t st = s->stream;
+  HIP_TRY(hipEventRecord(s->ev[0], st));
+  if (flags & KR_BASES_DEVICE) {
+    s->in.bases = bases;
+    s->in.offsets = offsets;
+  } else {
+    uint64_t nb = offsets[nreads];
+    if (nb > s->max_bases) return kr::fail(KR_ERR_ARG, "kr_batch_submit: more bases than the stream was created for");
+    memcpy(s->h_bases, bases, nb);
+    memcpy(s->h_offsets, offsets, ((uint64_t)nreads + 1) * 8);
+    HIP_TRY(hipMemcpyAsync(s->d_bases, s->h_bases, nb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_offsets, s->h_offsets, ((uint64_t)nreads + 1) * 8, hipMemcpyHostToDevice, st));
+    s->in.bases = s->d_bases;
+    s->in.offsets = s->d_offsets;
+  }
+  s->in.nreads = nreads;
+  HIP_TRY(hipMemsetAsync(s->out.counters, 0, 32, st));
+  HIP_TRY(hipEventRecord(s->ev[1], st));
+  const DevIndex& dix = s->ix->dix;
+  uint32_t grid = std::min(nreads, s->nwaves);
+  if (flags & KR_TAP_HITS) {
+    if (!s->h_hits) {
+      HIP_TRY(hipMalloc((void**)&s->out.hits, (uint64_t)s->hit_cap * sizeof(kr_hit)));
+      s->dallocs.push_back(s->out.hits);
+      HIP_TRY(hipHostMalloc((void**)&s->h_hits, (uint64_t)s->hit_cap * sizeof(kr_hit), hipHostMallocDefault));
+      s->hallocs.push_back(s->h_hits);
+    }
+    hipLaunchKernelGGL((kr_probe_kernel_t<false, true>), dim3(grid), dim3(kWave), probe_lds_bytes(false, s->dp.np), st, dix, s->dp, s->in, s->out);
+    hipLaunchKernelGGL((kr_probe_kernel_t<true, true>), dim3(s->ovf_waves), dim3(kWave), probe_lds_bytes(true, s->dp.np), st, dix, s->dp, s->in, s->out);
+  } else {
+    hipLaunchKernelGGL((kr_probe_kernel_t<false, false>), dim3(grid), dim3(kWave), probe_lds_bytes(false, s->dp.np), st, dix, s->dp, s->in, s->out);
+    hipLaunchKernelGGL((kr_probe_kernel_t<true, false>), dim3(s->ovf_waves), dim3(kWave), probe_lds_bytes(true, s->dp.np), st, dix, s->dp, s->in, s->out);
+  }
+  HIP_TRY(hipEventRecord(s->ev[2], st));
+  hipLaunchKernelGGL(kr_llh_kernel, dim3(1024), dim3(256), 0, st, s->llh, dix, s->out);
+  hipLaunchKernelGGL(kr_select_kernel, dim3((nreads + 255) / 256), dim3(256), 0, st, s->llh, dix, s->dp, s->out, nreads);
+  HIP_TRY(hipEventRecord(s->ev[3], st));
+  HIP_TRY(hipGetLastError());
+  return KR_OK;
+}
+
+int kr_batch_wait(kr_stream* s)
+{
+  if (!s || !s->submitted) return kr::fail(KR_ERR_STATE, "kr_batch_wait: nothing submitted");
+  if (s->waited) return KR_OK;
+  HIP_TRY(hipSetDevice(s->ix->device));
+  HIP_TRY(hipMemcpyAsync(s->h_counters, s->out.counters, 32, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->waited = true;
+  s->nrecs = std::min(s->h_counters[0], s->rec_cap);
+  s->nhits = std::min<uint64_t>(s->h_counters[3], s->hit_cap);
+  return check_errflags(s->h_counters[1]);
+}
+
+static void fill_view(kr_stream* s, kr_result_view* v, bool device)
+{
+  memset(v, 0, sizeof(*v));
+  v->nreads = s->nreads;
+  v->nrecs = s->nrecs;
+  if (device) {
+    v->read_off = s->out.rd_off, v->read_cnt = s->out.rd_cnt, v->read_onmers = s->out.rd_onmers, v->read_na = s->out.rd_na;
+    v->rec_key = s->out.rec_key, v->rec_sel = s->out.rec_sel, v->rec_d = s->out.rec_d, v->rec_v = s->out.rec_v;
+    v->rec_chisq = s->out.rec_chisq, v->rec_hist = s->out.rec_hist;
+  } else {
+    v->read_off = s->h_rd_off, v->read_cnt = s->h_rd_cnt, v->read_onmers = s->h_rd_onmers, v->read_na = s->h_rd_na;
+    v->rec_key = s->h_rec_key, v->rec_sel = s->h_rec_sel, v->rec_d = s->h_rec_d, v->rec_v = s->h_rec_v;
+    v->rec_chisq = s->h_rec_chisq, v->rec_hist = (s->flags & KR_TAP_ACCS) ? s->h_rec_hist : nullptr;
+  }
+}
+
+int kr_batch_collect(kr_stream* s, kr_result_view* v)
+{
+  kr::clear_error();
+  if (!s || !v) return kr::fail(KR_ERR_ARG, "kr_batch_collect: null argument");
+  int rc = kr_batch_wait(s);
+  if (rc) return rc;
+  hipStream_t st = s->stream;
+  uint64_t nr = s->nreads, nc = s->nrecs;
+  HIP_TRY(hipMemcpyAsync(s->h_rd_off, s->out.rd_off, nr * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(s->h_rd_cnt, s->out.rd_cnt, nr * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(s->h_rd_onmers, s->out.rd_onmers, nr * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(s->h_rd_filt, s->out.rd_filt, nr * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(s->h_rd_na, s->out.rd_na, nr, hipMemcpyDeviceToHost, st));
+  if (nc) {
+    HIP_TRY(hipMemcpyAsync(s->h_rec_key, s->out.rec_key, nc * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(s->h_rec_sel, s->out.rec_sel, nc, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(s->h_rec_d, s->out.rec_d, nc * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(s->h_rec_v, s->out.rec_v, nc * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(s->h_rec_chisq, s->out.rec_chisq, nc * 8, hipMemcpyDeviceToHost, st));
+    if (s->flags & KR_TAP_ACCS)
+      HIP_TRY(hipMemcpyAsync(s->h_rec_hist, s->out.rec_hist, nc * s->dp.np * 4, hipMemcpyDeviceToHost, st));
+  }
+  if ((s->flags & KR_TAP_HITS) && s->nhits)
+    HIP_TRY(hipMemcpyAsync(s->h_hits, s->out.hits, s->nhits * sizeof(kr_hit), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  fill_view(s, v, false);
+  uint64_t nrows = 0;
+  for (uint64_t i = 0; i < nc; ++i) nrows += s->h_rec_sel[i];
+  v->nrows = nrows;
+  return KR_OK;
+}
+
+int kr_batch_collect_device(kr_stream* s, kr_result_view* v)
+{
+  kr::clear_error();
+  if (!s || !v) return kr::fail(KR_ERR_ARG, "kr_batch_collect_device: null argument");
+  int rc = kr_batch_wait(s);
+  if (rc) return rc;
+  fill_view(s, v, true);
+  return KR_OK;
+}
+
+int kr_batch_hits(kr_stream* s, const kr_hit** hits, uint64_t* nhits)
+{
+  if (!s || !hits || !nhits || !s->waited) return kr::fail(KR_ERR_STATE, "kr_batch_hits: collect a KR_TAP_HITS batch first");
+  *hits = s->h_hits;
+  *nhits = s->nhits;
+  return KR_OK;
+}
+
+int kr_batch_readtaps(kr_stream* s, const kr_readtap** taps)
+{
+  if (!s || !taps || !s->waited) return kr::fail(KR_ERR_STATE, "kr_batch_readtaps: collect a batch first");
+  *taps = reinterpret_cast<const kr_readtap*>(s->h_rd_filt);
+  return KR_OK;
+}
+
+int kr_batch_timing(kr_stream* s, kr_timing* t)
+{
+  if (!s || !t || !s->waited) return kr::fail(KR_ERR_STATE, "kr_batch_timing: wait for a batch first");
+  memset(t, 0, sizeof(*t));
+  HIP_TRY(hipEventElapsedTime(&t->ms_h2d, s->ev[0], s->ev[1]));
+  HIP_TRY(hipEventElapsedTime(&t->ms_probe, s->ev[1], s->ev[2]));
+  HIP_TRY(hipEventElapsedTime(&t->ms_llh, s->ev[2], s->ev[3]));
+  t->ms_total = t->ms_probe + t->ms_llh;
+  t->overflow_reads = s->h_counters[2];
+  return KR_OK;
+}
+
+int kr_debug_front_end(const kr_index* ix, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads, uint32_t stride,
+                       uint32_t* rix, uint32_t* enc32, uint8_t* valid, uint8_t* pass)
+{
+  kr::clear_error();
+  if (!ix || !bases || !offsets || !rix || !enc32 || !valid || !pass || !nreads) return kr::fail(KR_ERR_ARG, "kr_debug_front_end: bad argument");
+  HIP_TRY(hipSetDevice(ix->device));
+  uint64_t nb = offsets[nreads], n = (uint64_t)nreads * stride * 2;
+  uint8_t *d_b = nullptr, *d_valid = nullptr, *d_pass = nullptr;
+  uint64_t* d_o = nullptr;
+  uint32_t *d_rix = nullptr, *d_enc = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_b, nb + 256));
+  HIP_TRY(hipMalloc((void**)&d_o, ((uint64_t)nreads + 1) * 8));
+  HIP_TRY(hipMalloc((void**)&d_rix, n * 4 + 16));
+  HIP_TRY(hipMalloc((void**)&d_enc, n * 4 + 16));
+  HIP_TRY(hipMalloc((void**)&d_valid, n + 16));
+  HIP_TRY(hipMalloc((void**)&d_pass, n + 16));
+  HIP_TRY(hipMemcpy(d_b, bases, nb, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_o, offsets, ((uint64_t)nreads + 1) * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(d_rix, 0, n * 4));
+  HIP_TRY(hipMemset(d_enc, 0, n * 4));
+  HIP_TRY(hipMemset(d_valid, 0, n));
+  HIP_TRY(hipMemset(d_pass, 0, n));
+  BatchIn in{d_b, d_o, nreads};
+  hipLaunchKernelGGL(kr_front_end_kernel, dim3(std::min(nreads, 4096u)), dim3(kWave), 0, 0, ix->dix, in, stride, d_rix, d_enc, d_valid, d_pass);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(rix, d_rix, n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(enc32, d_enc, n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(valid, d_valid, n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(pass, d_pass, n, hipMemcpyDeviceToHost));
+  hipFree(d_b), hipFree(d_o), hipFree(d_rix), hipFree(d_enc), hipFree(d_valid), hipFree(d_pass);
+  return KR_OK;
+}
+
+int kr_debug_brent(const kr_index* ix, uint32_t th, uint32_t n, const uint32_t* hist, const uint32_t* onmers, const double* rho,
+                   double* d_out, double* v_out)
+{
+  kr::clear_error();
+  if (!ix || !hist || !onmers || !rho || !d_out || !v_out || !n || th > KR_MAX_HDIST_TH) return kr::fail(KR_ERR_ARG, "kr_debug_brent: bad argument");
+  HIP_TRY(hipSetDevice(ix->device));
+  LlhConst C = make_llh_const(ix->dix.k, ix->dix.h, th);
+  uint32_t *d_h = nullptr, *d_on = nullptr;
+  double *d_rho = nullptr, *d_d = nullptr, *d_v = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_h, (uint64_t)n * (th + 1) * 4));
+  HIP_TRY(hipMalloc((void**)&d_on, (uint64_t)n * 4));
+  HIP_TRY(hipMalloc((void**)&d_rho, (uint64_t)n * 8));
+  HIP_TRY(hipMalloc((void**)&d_d, (uint64_t)n * 8));
+  HIP_TRY(hipMalloc((void**)&d_v, (uint64_t)n * 8));
+  HIP_TRY(hipMemcpy(d_h, hist, (uint64_t)n * (th + 1) * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_on, onmers, (uint64_t)n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_rho, rho, (uint64_t)n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(kr_brent_kernel, dim3((n + 127) / 128), dim3(128), 0, 0, C, n, d_h, d_on, d_rho, d_d, d_v);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(d_out, d_d, (uint64_t)n * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(v_out, d_v, (uint64_t)n * 8, hipMemcpyDeviceToHost));
+  hipFree(d_h), hipFree(d_on), hipFree(d_rho), hipFree(d_d), hipFree(d_v);
+  return KR_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,720 @@
+// kr_host.cpp — host side of the drop-in surface: on-disk index reader, backbone tree,
+// FASTA/FASTQ batcher and the `dist` report writer.  CPU only; no HIP in this file.
+//
+// Reference behaviour followed (file:line into bo1929/krepp v0.8.3):
+//   index directory discovery        src/krepp.cpp:66-108
+//   metadata / inc / cmer / crecord  src/krepp.cpp:18-29, src/index.cpp:51-158,
+//                                    src/table.cpp:65-75, src/record.cpp:203-211
+//   rho scaling                      src/index.cpp:188-201
+//   Newick numbering                 src/phytree.cpp:84-215,394-404
+//   balanced tree from a reflist     src/phytree.cpp:217-253
+//   FASTX records / batching         src/kseq.h:177-219, src/rqseq.cpp:180-197
+//   report text                      src/query.cpp:152-196, src/query.hpp:210
+#include "kr_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dirent.h>
+#include <cctype>
+#include <map>
+#include <memory>
+#include <set>
+#include <zlib.h>
+
+namespace kr {
+
+static thread_local std::string g_err;
+int fail(int code, const std::string& msg)
+{
+  g_err = msg;
+  return code;
+}
+void clear_error() { g_err.clear(); }
+
+// ---------------------------------------------------------------------------
+// MurmurHash3_x86_32 (public-domain algorithm by Austin Appleby), used by the
+// reference only to hash node names (src/record.hpp:26-47).
+// ---------------------------------------------------------------------------
+static inline uint32_t rol(uint32_t v, int s) { return (v << s) | (v >> (32 - s)); }
+static uint32_t mm3_32(const uint8_t* p, size_t n, uint32_t seed)
+{
+  uint32_t hsh = seed;
+  size_t nb = n >> 2;
+  for (size_t b = 0; b < nb; ++b) {
+    uint32_t kk = (uint32_t)p[4 * b] | ((uint32_t)p[4 * b + 1] << 8) | ((uint32_t)p[4 * b + 2] << 16) |
+                  ((uint32_t)p[4 * b + 3] << 24);
+    kk = rol(kk * 0xcc9e2d51u, 15) * 0x1b873593u;
+    hsh = rol(hsh ^ kk, 13) * 5u + 0xe6546b64u;
+  }
+  uint32_t kk = 0;
+  size_t rem = n & 3, base = nb * 4;
+  if (rem == 3) kk ^= (uint32_t)p[base + 2] << 16;
+  if (rem >= 2) kk ^= (uint32_t)p[base + 1] << 8;
+  if (rem >= 1) {
+    kk ^= p[base];
+    hsh ^= rol(kk * 0xcc9e2d51u, 15) * 0x1b873593u;
+  }
+  hsh ^= (uint32_t)n;
+  hsh ^= hsh >> 16;
+  hsh *= 0x85ebca6bu;
+  hsh ^= hsh >> 13;
+  hsh *= 0xc2b2ae35u;
+  hsh ^= hsh >> 16;
+  return hsh;
+}
+uint64_t leaf_name_hash(const std::string& name)
+{
+  const uint8_t* p = reinterpret_cast<const uint8_t*>(name.data());
+  return ((uint64_t)mm3_32(p, name.size(), 0) << 32) | mm3_32(p, name.size(), 1);
+}
+uint64_t rehash64(uint64_t sh)
+{
+  uint8_t b[8];
+  memcpy(b, &sh, 8);
+  return ((uint64_t)mm3_32(b, 8, 0) << 32) | mm3_32(b, 8, 1);
+}
+
+// ---------------------------------------------------------------------------
+// Tree
+// ---------------------------------------------------------------------------
+std::string HostTree::name(uint32_t se) const
+{
+  if (se == 0 || se >= nodes.size()) return "";
+  return nodes[se].label.empty() ? std::to_string(se - 1) : nodes[se].label;
+}
+
+namespace {
+
+// Token stream equivalent to Tree::split_nwk (src/phytree.cpp:84-148): structural
+// characters are tokens of their own; a label/length token (possibly empty) is
+// emitted in front of every ')' ':' ',' that does not directly follow '('.
+bool tokenize_newick(std::string s, std::vector<std::string>& tk, std::string& err)
+{
+  if (s.empty()) {
+    err = "Given Newick tree seems to be empty?!?.";
+    return false;
+  }
+  if (s.back() == '\n') s.pop_back();
+  if (s.empty() || s.back() != ';') {
+    err = "Given Newick tree ends with a character other than ';'.";
+    return false;
+  }
+  std::string cur;
+  bool in_quote = false, prev_was_quote = false, in_comment = false;
+  for (size_t i = 0; i < s.size(); ++i) {
+    const char c = s[i];
+    if (in_comment) {
+      if (c == ']') in_comment = false;
+      continue;
+    }
+    const bool is_q = (c == '\'' || c == '"');
+    if (is_q && prev_was_quote) { // doubled quote = literal quote character
+      in_quote = false;
+      cur += "'";
+      continue;
+    }
+    prev_was_quote = is_q;
+    if (is_q) {
+      in_quote = !in_quote;
+      continue;
+    }
+    if (in_quote) {
+      if (c == '[')
+        in_comment = true;
+      else
+        cur += c;
+      continue;
+    }
+    switch (c) {
+      case '(':
+        tk.emplace_back("(");
+        break;
+      case ')':
+      case ':':
+      case ',':
+        if (i == 0 || s[i - 1] != '(') {
+          tk.push_back(cur);
+          cur.clear();
+        }
+        tk.emplace_back(1, c);
+        break;
+      case '[':
+      case ']':
+        err = "Given Newick tree contains an unquoted label or length with '[' or ']'.";
+        return false;
+      case ';':
+        if (i + 1 == s.size()) {
+          i = s.size();
+          break;
+        }
+        err = "Given Newick tree contains an unquoted label or length with ';' (or several trees).";
+        return false;
+      default:
+        if ((c == ' ' || c == '\n') && !cur.empty()) {
+          err = "Given Newick tree contains an unquoted label or length with ' ' or newline.";
+          return false;
+        }
+        cur += c;
+    }
+  }
+  if (!cur.empty()) tk.push_back(cur);
+  return true;
+}
+
+struct NewickParser {
+  const std::vector<std::string>& tk;
+  size_t at = 0;
+  HostTree& t;
+  std::string err;
+  NewickParser(const std::vector<std::string>& tk_, HostTree& t_)
+    : tk(tk_), t(t_)
+  {}
+  bool is(size_t i, const char* s) const { return i < tk.size() && tk[i] == s; }
+
+  void label_and_length(TreeNode& nd)
+  { // src/phytree.cpp:177-188 (internal) == :193-204 (leaf)
+    nd.label.clear();
+    nd.blen = NAN;
+    if (at >= tk.size() || is(at, ",")) return;
+    if (!is(at, ":")) nd.label = tk[at++];
+    if (is(at, ":")) {
+      nd.blen = at + 1 < tk.size() ? atof(tk[at + 1].c_str()) : 0.0;
+      at += 2;
+    }
+  }
+
+  // Returns the se given to the subtree root; children get their numbers first
+  // (post-order), exactly as Node::parse assigns `se = ++nnodes` after its children.
+  uint32_t subtree()
+  {
+    TreeNode nd;
+    nd.parent = 0;
+    if (is(at, "(")) {
+      std::vector<uint32_t> kids;
+      do {
+        ++at;
+        uint32_t c = subtree();
+        if (!err.empty()) return 0;
+        kids.push_back(c);
+      } while (is(at, ","));
+      if (kids.size() == 1) {
+        err = "A node has a single child in the backbone tree! Please suppress unifurcations.";
+        return 0;
+      }
+      nd.kind = 2;
+      bool bare_close = false;
+      if (is(at, ")")) {
+        ++at;
+        bare_close = is(at, ")"); // src/phytree.cpp:173-175: return before reading a label
+      }
+      if (!bare_close) label_and_length(nd);
+      t.nodes.push_back(nd);
+      uint32_t se = (uint32_t)t.nodes.size() - 1;
+      for (uint32_t c : kids) t.nodes[c].parent = se;
+      return se;
+    }
+    label_and_length(nd);
+    nd.kind = 1;
+    t.nodes.push_back(nd);
+    return (uint32_t)t.nodes.size() - 1;
+  }
+};
+
+void balanced_rec(const std::vector<std::string>& names, size_t lo, size_t hi, HostTree& t, uint32_t& self)
+{
+  TreeNode nd;
+  nd.parent = 0;
+  nd.blen = 1.0;
+  if (hi - lo == 1) {
+    nd.kind = 1;
+    nd.label = names[lo];
+    t.nodes.push_back(nd);
+    self = (uint32_t)t.nodes.size() - 1;
+    return;
+  }
+  // second half first (src/phytree.cpp:235-243)
+  size_t mid = lo + (hi - lo) / 2;
+  uint32_t a = 0, b = 0;
+  balanced_rec(names, mid, hi, t, a);
+  balanced_rec(names, lo, mid, t, b);
+  nd.kind = 2;
+  t.nodes.push_back(nd);
+  self = (uint32_t)t.nodes.size() - 1;
+  t.nodes[a].parent = self;
+  t.nodes[b].parent = self;
+}
+
+} // namespace
+
+bool parse_newick(const std::string& text, HostTree& out, std::string& err)
+{
+  std::vector<std::string> tk;
+  if (!tokenize_newick(text, tk, err)) return false;
+  out.nodes.clear();
+  out.nodes.push_back(TreeNode{"", NAN, 0, 0});
+  NewickParser p(tk, out);
+  p.subtree();
+  if (!p.err.empty()) {
+    err = p.err;
+    return false;
+  }
+  return true;
+}
+
+void balanced_tree(const std::vector<std::string>& names, HostTree& out)
+{
+  out.nodes.clear();
+  out.nodes.push_back(TreeNode{"", NAN, 0, 0});
+  uint32_t root = 0;
+  if (!names.empty()) balanced_rec(names, 0, names.size(), out, root);
+}
+
+} // namespace kr
+
+// ---------------------------------------------------------------------------
+// kr_host_index
+// ---------------------------------------------------------------------------
+struct kr_host_lib {
+  std::string suffix;
+  std::vector<uint64_t> inc;
+  std::vector<uint32_t> cmer; // interleaved
+  std::vector<uint32_t> pse;  // interleaved
+  std::vector<double> rho;
+  uint32_t nnodes = 0, nsubsets = 0, r = 0, frac = 0, w = 0, nrows_meta = 0;
+};
+
+struct kr_host_index {
+  uint32_t k = 0, h = 0, m = 0;
+  std::vector<uint8_t> ppos, npos;
+  std::vector<kr_host_lib> libs;
+  kr::HostTree tree;
+  std::vector<std::string> names; // printable name per se
+  std::vector<uint8_t> kind;
+  bool wbackbone = false;
+  std::vector<kr_lib_view> lib_views;
+};
+
+namespace {
+
+bool slurp(const std::string& path, std::string& out)
+{
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize((size_t)std::max(0L, n));
+  size_t got = n > 0 ? fread(&out[0], 1, (size_t)n, f) : 0;
+  fclose(f);
+  return got == (size_t)std::max(0L, n);
+}
+
+template <typename T>
+bool take(const std::string& buf, size_t& off, T& v)
+{
+  if (off + sizeof(T) > buf.size()) return false;
+  memcpy(&v, buf.data() + off, sizeof(T));
+  off += sizeof(T);
+  return true;
+}
+
+template <typename T>
+bool read_array_file(const std::string& path, size_t header_bytes, void* header, std::vector<T>& out,
+                     uint64_t (*count_of)(const void*))
+{
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  bool ok = fread(header, 1, header_bytes, f) == header_bytes;
+  if (ok) {
+    uint64_t n = count_of(header);
+    out.resize(n);
+    ok = n == 0 || fread(out.data(), sizeof(T), n, f) == n;
+  }
+  fclose(f);
+  return ok;
+}
+
+} // namespace
+
+extern "C" {
+
+int kr_host_index_load(const char* index_dir, kr_host_index** out)
+{
+  kr::clear_error();
+  if (!index_dir || !out) return kr::fail(KR_ERR_ARG, "kr_host_index_load: null argument");
+  *out = nullptr;
+  static const std::set<std::string> known{"cmer", "crecord", "inc", "metadata", "tree", "reflist"};
+  DIR* d = opendir(index_dir);
+  if (!d) return kr::fail(KR_ERR_IO, std::string("cannot open index directory ") + index_dir);
+  // group files by everything after the type: "-m<M>r<R>-frac" (src/krepp.cpp:72-87)
+  std::map<std::string, std::set<std::string>> groups;
+  while (dirent* e = readdir(d)) {
+    std::string fn = e->d_name;
+    size_t p1 = fn.find('-');
+    if (p1 == std::string::npos) continue;
+    size_t p2 = fn.find('-', p1 + 1);
+    if (p2 == std::string::npos) continue;
+    if (!known.count(fn.substr(0, p1))) continue;
+    size_t dot = fn.rfind('.');
+    if (dot != std::string::npos && dot != 0) continue; // files with an extension are ignored
+    groups[fn.substr(p1)].insert(fn.substr(0, p1));
+  }
+  closedir(d);
+  if (groups.empty()) return kr::fail(KR_ERR_IO, std::string("no partial index in ") + index_dir);
+
+  std::unique_ptr<kr_host_index> hx(new kr_host_index());
+  const std::string dir = index_dir;
+  std::vector<std::string> first_order;
+  std::set<uint32_t> residues;
+  for (auto& g : groups) {
+    const std::string& sfx = g.first;
+    const std::set<std::string>& have = g.second;
+    bool core = have.count("cmer") && have.count("crecord") && have.count("inc") && have.count("metadata");
+    if (!core || !(have.count("tree") || have.count("reflist")))
+      return kr::fail(KR_ERR_FORMAT, "There is a partial index with a missing file!");
+
+    // --- tree (src/index.cpp:3-49)
+    kr::HostTree t;
+    if (have.count("tree")) {
+      std::string nwk, err;
+      if (!slurp(dir + "/tree" + sfx, nwk)) return kr::fail(KR_ERR_IO, "Failed to open " + dir + "/tree" + sfx);
+      if (!kr::parse_newick(nwk, t, err)) return kr::fail(KR_ERR_FORMAT, err);
+      hx->wbackbone = true;
+    } else {
+      std::string txt;
+      if (!slurp(dir + "/reflist" + sfx, txt))
+        return kr::fail(KR_ERR_IO, "Unable to open reference list file for an index without a tree.");
+      std::vector<std::string> names;
+      size_t a = 0;
+      while (a < txt.size()) {
+        size_t b = txt.find('\n', a);
+        if (b == std::string::npos) b = txt.size();
+        names.push_back(txt.substr(a, b - a));
+        a = b + 1;
+      }
+      kr::balanced_tree(names, t);
+      hx->wbackbone = false;
+    }
+    std::vector<std::string> order;
+    for (uint32_t se = 1; se <= t.nnodes(); ++se) order.push_back(t.nodes[se].label);
+    if (hx->libs.empty()) {
+      hx->tree = t;
+      first_order = order;
+    } else if (order != first_order) { // Tree::check_compatible (src/phytree.cpp:10-36)
+      return kr::fail(KR_ERR_FORMAT, "Partial libraries are based on different trees!");
+    }
+
+    // --- metadata (src/krepp.cpp:18-29; src/index.cpp:58-70)
+    std::string md;
+    if (!slurp(dir + "/metadata" + sfx, md)) return kr::fail(KR_ERR_IO, "Failed to open " + dir + "/metadata" + sfx);
+    size_t off = 0;
+    uint8_t k8, w8, h8, frac8;
+    uint32_t m32, r32, nrows32;
+    if (!(take(md, off, k8) && take(md, off, w8) && take(md, off, h8) && take(md, off, m32) && take(md, off, r32) &&
+          take(md, off, frac8) && take(md, off, nrows32)) ||
+        h8 > k8 || off + k8 > md.size())
+      return kr::fail(KR_ERR_FORMAT, "Failed to read the metadata of a partial index!");
+    std::vector<uint8_t> ppos(md.begin() + off, md.begin() + off + h8);
+    std::vector<uint8_t> npos(md.begin() + off + h8, md.begin() + off + k8);
+    if (k8 > 31 || k8 - h8 > 16 || m32 == 0)
+      return kr::fail(KR_ERR_FORMAT, "unsupported k/h/m in metadata" + sfx);
+    if (hx->libs.empty()) {
+      hx->k = k8, hx->h = h8, hx->m = m32;
+      hx->ppos = ppos, hx->npos = npos;
+    } else if (hx->k != k8 || hx->h != h8 || hx->m != m32 || hx->ppos != ppos || hx->npos != npos) {
+      return kr::fail(KR_ERR_FORMAT, "Partial libraries have incompatible hash functions!"); // src/lshf.cpp:159-180
+    }
+
+    kr_host_lib lib;
+    lib.suffix = sfx;
+    lib.r = r32, lib.frac = frac8 ? 1 : 0, lib.w = w8, lib.nrows_meta = nrows32;
+    // --- cmer + inc (src/table.cpp:65-75)
+    uint64_t nk = 0;
+    if (!read_array_file<uint32_t>(dir + "/cmer" + sfx, 8, &nk, lib.cmer,
+                                   [](const void* h) { return 2 * *(const uint64_t*)h; }))
+      return kr::fail(KR_ERR_IO, "Failed to read the k-mer vector of a partial index!");
+    uint32_t nr = 0;
+    if (!read_array_file<uint64_t>(dir + "/inc" + sfx, 4, &nr, lib.inc,
+                                   [](const void* h) { return (uint64_t) * (const uint32_t*)h; }))
+      return kr::fail(KR_ERR_IO, "Failed to read the offset array of a partial index!");
+    if (!lib.inc.empty() && lib.inc.back() > nk)
+      return kr::fail(KR_ERR_FORMAT, "inc" + sfx + " points past the end of cmer" + sfx);
+    // --- crecord (src/record.cpp:203-211)
+    {
+      std::string cr;
+      if (!slurp(dir + "/crecord" + sfx, cr)) return kr::fail(KR_ERR_IO, "Failed to open " + dir + "/crecord" + sfx);
+      size_t o = 0;
+      if (!take(cr, o, lib.nnodes) || !take(cr, o, lib.nsubsets) ||
+          cr.size() < o + (size_t)lib.nsubsets * 8 + (size_t)lib.nnodes * 8)
+        return kr::fail(KR_ERR_FORMAT, "Failed to read the color array of a partial index!");
+      lib.pse.resize((size_t)lib.nsubsets * 2);
+      memcpy(lib.pse.data(), cr.data() + o, (size_t)lib.nsubsets * 8);
+      o += (size_t)lib.nsubsets * 8;
+      lib.rho.resize(lib.nnodes);
+      memcpy(lib.rho.data(), cr.data() + o, (size_t)lib.nnodes * 8);
+    }
+    if (lib.nnodes != hx->tree.nnodes() + 1)
+      return kr::fail(KR_ERR_FORMAT, "crecord" + sfx + " does not match the tree (nnodes)");
+    // residues served by this library (src/index.cpp:144-157)
+    if (lib.frac) {
+      for (uint32_t q = 0; q <= lib.r; ++q) residues.insert(q);
+    } else {
+      residues.insert(lib.r);
+    }
+    hx->libs.push_back(std::move(lib));
+  }
+  // Index::make_rho_partial (src/index.cpp:188-201)
+  const double coef = (double)residues.size() / (double)hx->m;
+  for (auto& lib : hx->libs)
+    for (double& v : lib.rho) v *= coef;
+
+  uint32_t nn = hx->tree.nnodes();
+  hx->names.resize(nn + 1);
+  hx->kind.assign(nn + 1, 0);
+  for (uint32_t se = 1; se <= nn; ++se) {
+    hx->names[se] = hx->tree.name(se);
+    hx->kind[se] = hx->tree.nodes[se].kind;
+  }
+  for (auto& lib : hx->libs) {
+    kr_lib_view v;
+    memset(&v, 0, sizeof(v));
+    v.inc = lib.inc.data(), v.cmer = lib.cmer.data(), v.pse = lib.pse.data(), v.rho = lib.rho.data();
+    v.nkmers = lib.cmer.size() / 2, v.nrows = (uint32_t)lib.inc.size(), v.nsubsets = lib.nsubsets;
+    v.nnodes = lib.nnodes, v.r = lib.r, v.frac = lib.frac, v.w = lib.w;
+    hx->lib_views.push_back(v);
+  }
+  *out = hx.release();
+  return KR_OK;
+}
+
+void kr_host_index_free(kr_host_index* h) { delete h; }
+
+int kr_host_index_view(const kr_host_index* h, kr_index_view* v)
+{
+  if (!h || !v) return kr::fail(KR_ERR_ARG, "kr_host_index_view: null argument");
+  memset(v, 0, sizeof(*v));
+  v->k = h->k, v->h = h->h, v->m = h->m;
+  v->ppos = h->ppos.data(), v->npos = h->npos.data();
+  v->nlibs = (uint32_t)h->lib_views.size(), v->libs = h->lib_views.data();
+  v->tree_nnodes = h->tree.nnodes(), v->node_kind = h->kind.data();
+  v->wbackbone = h->wbackbone;
+  return KR_OK;
+}
+
+const char* kr_host_index_node_name(const kr_host_index* h, uint32_t se)
+{
+  return (h && se < h->names.size()) ? h->names[se].c_str() : "";
+}
+uint32_t kr_host_index_node_parent(const kr_host_index* h, uint32_t se)
+{
+  return (h && se < h->tree.nodes.size()) ? h->tree.nodes[se].parent : 0;
+}
+double kr_host_index_node_blen(const kr_host_index* h, uint32_t se)
+{
+  return (h && se && se < h->tree.nodes.size()) ? h->tree.nodes[se].blen : NAN;
+}
+
+void kr_params_default(kr_params* p)
+{ // src/krepp.hpp:206-221, src/krepp.cpp:635-644
+  p->hdist_th = 4;
+  p->tau = 2;
+  p->chisq = 2.706;
+  p->dist_max = NAN;
+  p->multi = 1;
+  p->no_filter = 1;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// FASTA/FASTQ batcher.  Record grammar is kseq's (src/kseq.h:177-219):
+//  - a record starts at the next '>' or '@';
+//  - the name runs to the first whitespace, the rest of the line is a comment;
+//  - sequence bytes are every isgraph() byte up to the next '>', '+' or '@'
+//    (wherever it occurs, not only at line starts);
+//  - after '+' the rest of that line is skipped and quality bytes (33..127) are
+//    read until as many as the sequence have been seen; one further byte is
+//    consumed; a short quality string ends reading like EOF (return -2 is < 0,
+//    src/rqseq.cpp:189).
+// ---------------------------------------------------------------------------
+struct kr_fastx {
+  gzFile f = nullptr;
+  std::vector<unsigned char> buf;
+  size_t pos = 0, end = 0;
+  bool eof = false;
+  int last_char = 0;
+  bool done = false;
+  // current batch
+  std::vector<uint8_t> bases;
+  std::vector<uint64_t> offsets;
+  std::string name_blob;
+  std::vector<size_t> name_off;
+  std::vector<const char*> name_ptrs;
+
+  int getc()
+  {
+    if (pos >= end) {
+      if (eof) return -1;
+      int n = gzread(f, buf.data(), (unsigned)buf.size());
+      if (n <= 0) {
+        eof = true;
+        return -1;
+      }
+      pos = 0;
+      end = (size_t)n;
+    }
+    return buf[pos++];
+  }
+
+  // returns sequence length, or <0 at end of input / truncated record
+  long next_record(std::string& name, std::vector<uint8_t>& seq_out)
+  {
+    int c;
+    if (last_char == 0) {
+      while ((c = getc()) != -1 && c != '>' && c != '@') {
+      }
+      if (c == -1) return -1;
+      last_char = c;
+    }
+    name.clear();
+    // name: up to first whitespace; a stream that ends right after the marker is EOF
+    c = getc();
+    if (c == -1) return -1;
+    while (c != -1 && !isspace(c)) {
+      name.push_back((char)c);
+      c = getc();
+    }
+    if (c != -1 && c != '\n') {
+      while ((c = getc()) != -1 && c != '\n') {
+      }
+    }
+    size_t l0 = seq_out.size();
+    while ((c = getc()) != -1 && c != '>' && c != '+' && c != '@') {
+      if (isgraph(c)) seq_out.push_back((uint8_t)c);
+    }
+    if (c == '>' || c == '@') last_char = c;
+    long slen = (long)(seq_out.size() - l0);
+    if (c != '+') return slen; // FASTA (or last record)
+    while ((c = getc()) != -1 && c != '\n') {
+    }
+    if (c == -1) {
+      seq_out.resize(l0);
+      return -2;
+    }
+    long ql = 0;
+    while ((c = getc()) != -1 && ql < slen)
+      if (c >= 33 && c <= 127) ql++;
+    last_char = 0;
+    if (ql != slen) {
+      seq_out.resize(l0);
+      return -2;
+    }
+    return slen;
+  }
+};
+
+extern "C" {
+
+int kr_fastx_open(const char* path, kr_fastx** out)
+{
+  kr::clear_error();
+  if (!path || !out) return kr::fail(KR_ERR_ARG, "kr_fastx_open: null argument");
+  gzFile f = gzopen(path, "rb");
+  if (!f) return kr::fail(KR_ERR_IO, std::string("Failed to open the file at ") + path); // src/rqseq.cpp:174-176
+  gzbuffer(f, 1 << 20);
+  kr_fastx* r = new kr_fastx();
+  r->f = f;
+  r->buf.resize(1 << 20);
+  *out = r;
+  return KR_OK;
+}
+
+// QSeq::read_next_batch (src/rqseq.cpp:180-197): keep reading until the batch holds
+// at least `min_bases` bases (reference: RBATCH_SIZE*DSEQ_LEN = 76,800) or input ends.
+int kr_fastx_next(kr_fastx* r, uint64_t min_bases, kr_fastx_batch* out)
+{
+  if (!r || !out) return kr::fail(KR_ERR_ARG, "kr_fastx_next: null argument");
+  r->bases.clear();
+  r->offsets.assign(1, 0);
+  r->name_blob.clear();
+  r->name_off.clear();
+  std::string name;
+  bool cont = false;
+  uint64_t bpc = 0;
+  while (!r->done && bpc < min_bases) {
+    long l = r->next_record(name, r->bases);
+    cont = l >= 0;
+    if (!cont) {
+      r->done = true;
+      break;
+    }
+    bpc += (uint64_t)l;
+    r->offsets.push_back(r->bases.size());
+    r->name_off.push_back(r->name_blob.size());
+    r->name_blob += name;
+    r->name_blob.push_back('\0');
+  }
+  r->name_ptrs.resize(r->name_off.size());
+  for (size_t i = 0; i < r->name_off.size(); ++i) r->name_ptrs[i] = r->name_blob.c_str() + r->name_off[i];
+  out->bases = r->bases.data();
+  out->offsets = r->offsets.data();
+  out->names = r->name_ptrs.data();
+  out->nreads = (uint32_t)r->name_off.size();
+  out->more = r->done ? 0 : 1;
+  return KR_OK;
+}
+
+void kr_fastx_close(kr_fastx* r)
+{
+  if (!r) return;
+  if (r->f) gzclose(r->f);
+  delete r;
+}
+
+// report_distances (src/query.cpp:158-196), non-summarize branch.  The selection
+// (multi / filter / dist-max / closest) was already made on the device: rec_sel.
+int kr_format_dist(const kr_host_index* h, const kr_result_view* rv, const char* const* names, char** text,
+                   uint64_t* len)
+{
+  if (!h || !rv || !text || !len) return kr::fail(KR_ERR_ARG, "kr_format_dist: null argument");
+  std::string s;
+  s.reserve((size_t)rv->nreads * 48);
+  char num[64];
+  for (uint32_t r = 0; r < rv->nreads; ++r) {
+    const char* id = names ? names[r] : "";
+    uint32_t o = rv->read_off[r], n = rv->read_cnt[r], emitted = 0;
+    for (uint32_t i = o; i < o + n; ++i) {
+      if (!rv->rec_sel[i]) continue;
+      uint32_t se = rv->rec_key[i] >> 1;
+      snprintf(num, sizeof(num), "%.5f", rv->rec_d[i]);
+      s += id;
+      s += '\t';
+      s += kr_host_index_node_name(h, se);
+      s += '\t';
+      s += num;
+      s += '\n';
+      emitted++;
+    }
+    (void)emitted;
+    if (rv->read_na[r]) { // src/query.cpp:173-176
+      s += id;
+      s += "\tNA\tNaN\n";
+    }
+  }
+  char* p = (char*)malloc(s.size() + 1);
+  if (!p) return kr::fail(KR_ERR_NOMEM, "kr_format_dist: out of memory");
+  memcpy(p, s.c_str(), s.size() + 1);
+  *text = p;
+  *len = s.size();
+  return KR_OK;
+}
+
+void kr_free(void* p) { free(p); }
+
+const char* kr_last_error(void) { return kr::g_err.c_str(); }
+const char* kr_version(void) { return "krepp-amd 0.1.0 (mirrors krepp v0.8.3 dist)"; }
+
+} // extern "C"

@@ -1,0 +1,185 @@
+"""Deterministic synthetic inputs: genomes evolved down a tree, reads
+sampled from them, and a direct large-index generator for the HBM-resident configs.
+
+PRNG = SplitMix64 over a counter (vectorised in numpy), so the data do not depend on the
+numpy version.  Nothing here is on the product path; it only makes inputs.
+"""
+from __future__ import annotations
+
+import os
+import re
+
+import numpy as np
+
+_M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(x):
+    """SplitMix64 output function applied element-wise to a uint64 array of counters."""
+    with np.errstate(over="ignore"):
+        z = (np.asarray(x, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+class Rng:
+    """Counter-based stream: stream id and seed select a 2^40-long block of counters."""
+
+    def __init__(self, seed, stream=0):
+        self.base = np.uint64(int(splitmix64(np.uint64((seed << 20) ^ stream))) & 0xFFFFFF0000000000)
+        self.pos = 0
+
+    def u64(self, n):
+        with np.errstate(over="ignore"):
+            c = self.base + np.arange(self.pos, self.pos + n, dtype=np.uint64)
+        self.pos += n
+        return splitmix64(c)
+
+    def uniform(self, n):
+        return (self.u64(n) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+    def below(self, n, bound):
+        return (self.u64(n) % np.uint64(bound)).astype(np.int64)
+
+
+BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+COMP = np.zeros(256, np.uint8)
+COMP[:] = ord("N")
+for a, b in zip(b"ACGTacgt", b"TGCAtgca"):
+    COMP[a] = b
+
+
+def parse_newick_simple(text):
+    """Minimal Newick reader for generating data: returns (children, names, blens, root)."""
+    text = text.strip().rstrip(";")
+    children, names, blens = {}, {}, {}
+    stack, cur, nid = [], None, 0
+    tok = re.findall(r"\(|\)|,|[^(),]+", text)
+    last_closed = None
+    root = None
+    for t in tok:
+        if t == "(":
+            node = nid
+            nid += 1
+            children[node] = []
+            names[node], blens[node] = "", 0.0
+            if stack:
+                children[stack[-1]].append(node)
+            stack.append(node)
+            last_closed = None
+        elif t == ",":
+            last_closed = None
+        elif t == ")":
+            last_closed = stack.pop()
+            root = last_closed
+        else:
+            label, _, bl = t.partition(":")
+            if last_closed is not None:
+                node = last_closed
+            else:
+                node = nid
+                nid += 1
+                children[node] = []
+                children[stack[-1]].append(node)
+            names[node] = label
+            blens[node] = float(bl) if bl else 0.0
+            last_closed = None
+    return children, names, blens, root
+
+
+def evolve_genomes(nwk_text, length, seed, cap=0.6):
+    """Substitution-only evolution of a random root sequence down the tree (JC69)."""
+    children, names, blens, root = parse_newick_simple(nwk_text)
+    rng = Rng(seed, 1)
+    seqs = {root: rng.below(length, 4).astype(np.uint8)}
+    out = {}
+    order = [root]
+    while order:
+        nd = order.pop()
+        if not children[nd]:
+            out[names[nd]] = BASES[seqs[nd]]
+        for c in children[nd]:
+            b = min(blens[c], cap)
+            p = 0.75 * (1.0 - np.exp(-4.0 / 3.0 * b))
+            s = seqs[nd].copy()
+            mut = rng.uniform(length) < p
+            s[mut] = (s[mut] + 1 + rng.below(int(mut.sum()), 3).astype(np.uint8)) & 3
+            seqs[c] = s
+            order.append(c)
+        del seqs[nd]
+    return out
+
+
+def write_fasta(path, name, seq, width=80, contigs=1):
+    n = len(seq)
+    with open(path, "wb") as f:
+        for c in range(contigs):
+            a, b = n * c // contigs, n * (c + 1) // contigs
+            f.write(b">" + f"{name}_c{c}".encode() + b"\n")
+            s = seq[a:b]
+            for i in range(0, len(s), width):
+                f.write(s[i:i + width].tobytes() + b"\n")
+
+
+def write_genomes(genomes, out_dir, contigs=1):
+    """Write one FASTA per genome + input_map.tsv (name <TAB> path); returns the tsv path."""
+    os.makedirs(out_dir, exist_ok=True)
+    tsv = os.path.join(out_dir, "input_map.tsv")
+    with open(tsv, "w") as f:
+        for name, seq in genomes.items():
+            p = os.path.join(out_dir, f"{name}.fna")
+            write_fasta(p, name, seq, contigs=contigs)
+            f.write(f"{name}\t{p}\n")
+    return tsv
+
+
+DIVERGENCE_MIX = [(0.20, 0.0), (0.30, 0.01), (0.30, 0.05), (0.10, 0.15), (0.10, None)]  # None = unrelated
+
+
+def sample_reads(genomes, nreads, seed, length=150, n_frac=0.01, mix=DIVERGENCE_MIX):
+    """SURVEY.md §8d config 2 reads: genome i = u mod N, uniform offset, strand flip 0.5, per-base
+    substitution rate from `mix`, one 'N' in `n_frac` of the reads.  Returns (bases, offsets, names)."""
+    rng = Rng(seed, 2)
+    gl = list(genomes.values())
+    ng = len(gl)
+    glen = np.array([len(g) for g in gl])
+    gi = rng.below(nreads, ng)
+    off = (rng.uniform(nreads) * (glen[gi] - length)).astype(np.int64)
+    flip = rng.uniform(nreads) < 0.5
+    u = rng.uniform(nreads)
+    cum = np.cumsum([m[0] for m in mix])
+    cls = np.searchsorted(cum, u, side="right").clip(0, len(mix) - 1)
+    rates = np.array([m[1] if m[1] is not None else -1.0 for m in mix])[cls]
+    allg = np.concatenate(gl)
+    gstart = np.concatenate([[0], np.cumsum(glen)[:-1]])
+    idx = (gstart[gi] + off)[:, None] + np.arange(length)[None, :]
+    reads = allg[idx]  # (nreads, length) uint8 ASCII
+    codes = np.searchsorted(BASES, reads).astype(np.uint8)
+    # substitutions
+    mut = rng.uniform(nreads * length).reshape(nreads, length) < np.where(rates >= 0, rates, 0.0)[:, None]
+    shift = (1 + rng.below(nreads * length, 3)).astype(np.uint8).reshape(nreads, length)
+    codes = np.where(mut, (codes + shift) & 3, codes)
+    unrelated = rates < 0
+    rnd = rng.below(nreads * length, 4).astype(np.uint8).reshape(nreads, length)
+    codes = np.where(unrelated[:, None], rnd, codes)
+    reads = BASES[codes]
+    # reverse complement
+    rc = COMP[reads[:, ::-1]]
+    reads = np.where(flip[:, None], rc, reads)
+    # one N in a fraction of reads
+    hasn = rng.uniform(nreads) < n_frac
+    npos = rng.below(nreads, length)
+    rows = np.nonzero(hasn)[0]
+    reads[rows, npos[rows]] = ord("N")
+    bases = np.ascontiguousarray(reads).reshape(-1)
+    offsets = (np.arange(nreads + 1, dtype=np.uint64) * np.uint64(length))
+    names = [f"r{i}_g{gi[i]}_{'u' if unrelated[i] else rates[i]}" for i in range(nreads)] if nreads <= 200000 else None
+    return bases, offsets, names
+
+
+def write_fastq(path, bases, offsets, names):
+    with open(path, "wb") as f:
+        for i, nm in enumerate(names):
+            s = bases[int(offsets[i]):int(offsets[i + 1])].tobytes()
+            f.write(b"@" + nm.encode() + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n")
