@@ -145,9 +145,12 @@ KR_API void kr_params_default(kr_params*);
 
 typedef struct kr_stream kr_stream;
 
-/* max_reads / max_bases bound one submitted batch; buffers are sized once. */
+/* max_reads / max_bases bound one submitted batch; device buffers are sized once.
+ * max_records bounds the (read, strand, leaf) accumulators one batch may emit
+ * (0 = default: max_reads * min(16, max(8, tree nodes + 1))); a batch that needs more
+ * fails with KR_ERR_CAPACITY and can be resubmitted in smaller pieces. */
 KR_API int kr_stream_create(const kr_index*, const kr_params*, uint32_t max_reads, uint64_t max_bases,
-                            kr_stream** out);
+                            uint64_t max_records, kr_stream** out);
 KR_API void kr_stream_destroy(kr_stream*);
 
 #define KR_BASES_HOST 0u
@@ -216,11 +219,11 @@ KR_API int kr_debug_brent(const kr_index*, uint32_t hdist_th, uint32_t n, const 
 /* Kernel timing of the last collected batch (HIP events on the stream's own stream). */
 typedef struct kr_timing {
   float ms_total;    /* first kernel start -> last kernel end                        */
-  float ms_probe;    /* probe/expand/accumulate kernel(s) (dominant)                 */
+  float ms_probe;    /* kr_probe_kernel (LDS accumulators; the dominant kernel)      */
+  float ms_overflow; /* kr_probe_kernel, global-accumulator pass over overflow reads */
   float ms_llh;      /* likelihood + selection kernels                               */
   float ms_h2d;      /* host->device copies (0 with KR_BASES_DEVICE)                 */
   uint32_t overflow_reads; /* reads that took the global-memory accumulator path     */
-  uint32_t pad;
 } kr_timing;
 KR_API int kr_batch_timing(kr_stream*, kr_timing* out);
 

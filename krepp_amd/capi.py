@@ -61,8 +61,8 @@ class KrHit(C.Structure):
 
 
 class KrTiming(C.Structure):
-    _fields_ = [("ms_total", C.c_float), ("ms_probe", C.c_float), ("ms_llh", C.c_float), ("ms_h2d", C.c_float),
-                ("overflow_reads", C.c_uint32), ("pad", C.c_uint32)]
+    _fields_ = [("ms_total", C.c_float), ("ms_probe", C.c_float), ("ms_overflow", C.c_float), ("ms_llh", C.c_float),
+                ("ms_h2d", C.c_float), ("overflow_reads", C.c_uint32)]
 
 
 class KrFastxBatch(C.Structure):
@@ -127,7 +127,7 @@ def load():
     lib.kr_index_device_bytes.restype = C.c_uint64
     lib.kr_params_default.argtypes = [C.POINTER(KrParams)]
     lib.kr_params_default.restype = None
-    lib.kr_stream_create.argtypes = [vp, C.POINTER(KrParams), C.c_uint32, C.c_uint64, C.POINTER(vp)]
+    lib.kr_stream_create.argtypes = [vp, C.POINTER(KrParams), C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     lib.kr_stream_destroy.argtypes = [vp]
     lib.kr_stream_destroy.restype = None
     lib.kr_batch_submit.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32]
@@ -260,8 +260,8 @@ class DeviceIndex:
     def device_bytes(self):
         return int(self.lib.kr_index_device_bytes(self.h))
 
-    def stream(self, params=None, max_reads=1 << 16, max_bases=None):
-        return Stream(self, params or default_params(), max_reads, max_bases or max_reads * 160)
+    def stream(self, params=None, max_reads=1 << 16, max_bases=None, max_records=0):
+        return Stream(self, params or default_params(), max_reads, max_bases or max_reads * 160, max_records)
 
     def front_end(self, bases, offsets, stride):
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
@@ -326,12 +326,12 @@ class Result:
 
 
 class Stream:
-    def __init__(self, dindex, params, max_reads, max_bases):
+    def __init__(self, dindex, params, max_reads, max_bases, max_records=0):
         self.lib = load()
         self.ix = dindex
         self.params = params
         self.h = C.c_void_p()
-        check(self.lib.kr_stream_create(dindex.h, C.byref(params), int(max_reads), int(max_bases), C.byref(self.h)))
+        check(self.lib.kr_stream_create(dindex.h, C.byref(params), int(max_reads), int(max_bases), int(max_records), C.byref(self.h)))
         self._keep = None
         self._flags = 0
 

@@ -35,6 +35,7 @@
 
 #include "kr_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -1346,7 +1347,7 @@ struct kr_stream {
   DevParams dp;
   LlhConst llh;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t max_reads = 0;
   uint64_t max_bases = 0;
   uint32_t rec_cap = 0, hit_cap = 0;
@@ -1368,6 +1369,7 @@ struct kr_stream {
   kr_hit* h_hits = nullptr;
   std::vector<void*> hallocs;
   // state
+  uint64_t h_rec_cap = 0; // pinned record buffers grow on demand in kr_batch_collect
   bool submitted = false, waited = false;
   uint32_t nreads = 0, flags = 0, nrecs = 0;
   uint64_t nhits = 0;
@@ -1411,7 +1413,8 @@ int check_errflags(uint32_t e)
 
 extern "C" {
 
-int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads, uint64_t max_bases, kr_stream** out)
+int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads, uint64_t max_bases, uint64_t max_records,
+                     kr_stream** out)
 {
   kr::clear_error();
   if (!ix || !p || !out || max_reads == 0) return kr::fail(KR_ERR_ARG, "kr_stream_create: bad argument");
@@ -1432,8 +1435,9 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   s->ovf_waves = (uint32_t)prop.multiProcessorCount * 2u;
   uint32_t nleaves2 = 2u * (ix->dix.tree_nnodes + 1);
   uint32_t g_slots = std::min<uint32_t>(next_pow2(std::max<uint32_t>(256u, 2u * nleaves2)), 1u << 16);
-  uint64_t per_read = std::min<uint64_t>(64, std::max<uint64_t>(8, (uint64_t)ix->dix.tree_nnodes + 1)); // <= 2 * leaves
-  uint64_t rc64 = std::max<uint64_t>(1u << 16, (uint64_t)max_reads * per_read);
+  // default record capacity: up to 2 * leaves per read, at most 16 per read on average
+  uint64_t per_read = std::min<uint64_t>(16, std::max<uint64_t>(8, (uint64_t)ix->dix.tree_nnodes + 1));
+  uint64_t rc64 = max_records ? max_records : std::max<uint64_t>(1u << 16, (uint64_t)max_reads * per_read);
   s->rec_cap = (uint32_t)std::min<uint64_t>(rc64, 1ull << 30);
   s->hit_cap = 1u << 22;
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -1480,12 +1484,6 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   HA(s->h_rd_onmers, max_reads);
   HA(s->h_rd_filt, 2ull * max_reads);
   HA(s->h_rd_na, max_reads);
-  HA(s->h_rec_key, s->rec_cap);
-  HA(s->h_rec_hist, (uint64_t)s->rec_cap * np);
-  HA(s->h_rec_sel, s->rec_cap);
-  HA(s->h_rec_d, s->rec_cap);
-  HA(s->h_rec_v, s->rec_cap);
-  HA(s->h_rec_chisq, s->rec_cap);
 #undef SA
 #undef HA
   *out = s.release();
@@ -1544,15 +1542,17 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
       s->hallocs.push_back(s->h_hits);
     }
     hipLaunchKernelGGL((kr_probe_kernel_t<false, true>), dim3(grid), dim3(kWave), probe_lds_bytes(false, s->dp.np), st, dix, s->dp, s->in, s->out);
+    HIP_TRY(hipEventRecord(s->ev[2], st));
     hipLaunchKernelGGL((kr_probe_kernel_t<true, true>), dim3(s->ovf_waves), dim3(kWave), probe_lds_bytes(true, s->dp.np), st, dix, s->dp, s->in, s->out);
   } else {
     hipLaunchKernelGGL((kr_probe_kernel_t<false, false>), dim3(grid), dim3(kWave), probe_lds_bytes(false, s->dp.np), st, dix, s->dp, s->in, s->out);
+    HIP_TRY(hipEventRecord(s->ev[2], st));
     hipLaunchKernelGGL((kr_probe_kernel_t<true, false>), dim3(s->ovf_waves), dim3(kWave), probe_lds_bytes(true, s->dp.np), st, dix, s->dp, s->in, s->out);
   }
-  HIP_TRY(hipEventRecord(s->ev[2], st));
+  HIP_TRY(hipEventRecord(s->ev[3], st));
   hipLaunchKernelGGL(kr_llh_kernel, dim3(1024), dim3(256), 0, st, s->llh, dix, s->out);
   hipLaunchKernelGGL(kr_select_kernel, dim3((nreads + 255) / 256), dim3(256), 0, st, s->llh, dix, s->dp, s->out, nreads);
-  HIP_TRY(hipEventRecord(s->ev[3], st));
+  HIP_TRY(hipEventRecord(s->ev[4], st));
   HIP_TRY(hipGetLastError());
   return KR_OK;
 }
@@ -1594,6 +1594,21 @@ int kr_batch_collect(kr_stream* s, kr_result_view* v)
   if (rc) return rc;
   hipStream_t st = s->stream;
   uint64_t nr = s->nreads, nc = s->nrecs;
+  if (nc > s->h_rec_cap) { // (re)allocate pinned record buffers
+    uint64_t cap = std::max<uint64_t>(nc + nc / 4, 1u << 16);
+    void** olds[] = {(void**)&s->h_rec_key, (void**)&s->h_rec_hist, (void**)&s->h_rec_sel, (void**)&s->h_rec_d, (void**)&s->h_rec_v, (void**)&s->h_rec_chisq};
+    for (void** o : olds)
+      if (*o) {
+        s->hallocs.erase(std::remove(s->hallocs.begin(), s->hallocs.end(), *o), s->hallocs.end());
+        (void)hipHostFree(*o);
+        *o = nullptr;
+      }
+    int rc2 = 0;
+    if ((rc2 = halloc(s, &s->h_rec_key, cap)) || (rc2 = halloc(s, &s->h_rec_hist, cap * s->dp.np)) || (rc2 = halloc(s, &s->h_rec_sel, cap)) ||
+        (rc2 = halloc(s, &s->h_rec_d, cap)) || (rc2 = halloc(s, &s->h_rec_v, cap)) || (rc2 = halloc(s, &s->h_rec_chisq, cap)))
+      return rc2;
+    s->h_rec_cap = cap;
+  }
   HIP_TRY(hipMemcpyAsync(s->h_rd_off, s->out.rd_off, nr * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(s->h_rd_cnt, s->out.rd_cnt, nr * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(s->h_rd_onmers, s->out.rd_onmers, nr * 4, hipMemcpyDeviceToHost, st));
@@ -1649,8 +1664,9 @@ int kr_batch_timing(kr_stream* s, kr_timing* t)
   memset(t, 0, sizeof(*t));
   HIP_TRY(hipEventElapsedTime(&t->ms_h2d, s->ev[0], s->ev[1]));
   HIP_TRY(hipEventElapsedTime(&t->ms_probe, s->ev[1], s->ev[2]));
-  HIP_TRY(hipEventElapsedTime(&t->ms_llh, s->ev[2], s->ev[3]));
-  t->ms_total = t->ms_probe + t->ms_llh;
+  HIP_TRY(hipEventElapsedTime(&t->ms_overflow, s->ev[2], s->ev[3]));
+  HIP_TRY(hipEventElapsedTime(&t->ms_llh, s->ev[3], s->ev[4]));
+  HIP_TRY(hipEventElapsedTime(&t->ms_total, s->ev[1], s->ev[4]));
   t->overflow_reads = s->h_counters[2];
   return KR_OK;
 }

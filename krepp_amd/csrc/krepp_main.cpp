@@ -1,0 +1,312 @@
+// krepp_main.cpp — the `krepp` command line for the sub-commands this repository
+// implements: `dist` (MI355X) and `index` (CPU).  Option names, defaults, header lines
+// and error conventions follow the reference CLI (src/krepp.cpp:508-712,
+// src/krepp.hpp:206-221); everything else of the reference CLI (place, seek, sketch,
+// inspect) is out of scope here and reported as such.
+//
+// `dist` pipeline: reader thread (gz/FASTX, src/rqseq.cpp:180-197) -> one worker per GPU,
+// each with its own replica of the index and its own kr_stream -> writer emitting batches
+// in INPUT order (the reference emits in task-completion order, src/krepp.cpp:368-383).
+#include "krepp_amd.h"
+
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#define KREPP_VERSION "v0.8.3"
+
+[[noreturn]] static void error_exit(const std::string& msg)
+{ // src/common.cpp:20-24
+  fprintf(stderr, "[ERROR] %s\n", msg.c_str());
+  exit(EXIT_FAILURE);
+}
+
+struct Args {
+  std::string sub;
+  std::map<std::string, std::string> opt;
+  std::map<std::string, bool> flag;
+  bool has(const std::string& k) const { return opt.count(k) != 0; }
+  std::string get(const std::string& k, const std::string& d = "") const
+  {
+    auto it = opt.find(k);
+    return it == opt.end() ? d : it->second;
+  }
+};
+
+static const std::map<std::string, std::string> kAlias = {
+  {"-i", "--index-dir"}, {"-q", "--query"}, {"-o", "--output-path"}, {"-t", "--nwk-file"}, {"-k", "--kmer-len"},
+  {"-w", "--win-len"}, {"-h", "--num-positions"}, {"-m", "--modulo-lsh"}, {"-r", "--residue-lsh"},
+};
+static const char* kFlags[] = {"--multi", "--filter", "--summarize", "--frac", "--verbose"};
+
+static Args parse(int argc, char** argv)
+{
+  Args a;
+  for (int i = 1; i < argc; ++i) {
+    std::string t = argv[i];
+    if (t == "--help") {
+      printf("krepp (MI355X build): sub-commands `dist` and `index`; see INTEGRATION.md\n");
+      exit(0);
+    }
+    if (t[0] != '-') {
+      if (a.sub.empty()) {
+        a.sub = t;
+        continue;
+      }
+      error_exit("Unexpected argument: " + t);
+    }
+    auto al = kAlias.find(t);
+    if (al != kAlias.end()) t = al->second;
+    bool is_flag = false;
+    for (const char* f : kFlags) {
+      std::string pos = f, neg = std::string("--no-") + (f + 2);
+      if (t == pos || t == neg) {
+        a.flag[pos] = (t == pos);
+        is_flag = true;
+      }
+    }
+    if (is_flag) continue;
+    if (i + 1 >= argc) error_exit("Option " + t + " requires a value");
+    a.opt[t] = argv[++i];
+  }
+  return a;
+}
+
+struct Job {
+  uint64_t seq = 0;
+  std::vector<uint8_t> bases;
+  std::vector<uint64_t> offsets;
+  std::vector<std::string> names;
+  std::string text;
+  bool done = false;
+};
+
+static int run_dist(const Args& a, const std::string& invocation)
+{
+  if (!a.has("--query") || !a.has("--index-dir")) error_exit("dist requires -q/--query and -i/--index-dir");
+  if (a.flag.count("--summarize") && a.flag.at("--summarize"))
+    error_exit("--summarize is not implemented in this build");
+  kr_params p;
+  kr_params_default(&p);
+  if (a.has("--hdist-th")) p.hdist_th = (uint32_t)atoi(a.get("--hdist-th").c_str());
+  if (a.has("--chisq")) p.chisq = atof(a.get("--chisq").c_str());
+  if (a.has("--dist-max")) {
+    p.dist_max = atof(a.get("--dist-max").c_str());
+    if (!(p.dist_max >= 1e-8 && p.dist_max <= 0.33)) error_exit("--dist-max: value not in range [1e-08, 0.33]");
+  }
+  if (a.flag.count("--multi")) p.multi = a.flag.at("--multi");
+  if (a.flag.count("--filter")) p.no_filter = !a.flag.at("--filter");
+  int ngpus = a.has("--gpus") ? atoi(a.get("--gpus").c_str()) : 1;
+  int dev0 = a.has("--device") ? atoi(a.get("--device").c_str()) : 0;
+  if (ngpus < 1) ngpus = 1;
+
+  FILE* out = stdout;
+  if (a.has("--output-path")) {
+    out = fopen(a.get("--output-path").c_str(), "w");
+    if (!out) error_exit("Failed to open " + a.get("--output-path"));
+  }
+  fprintf(stderr, "Loading the index and initializing...\n");
+  kr_host_index* hx = nullptr;
+  if (kr_host_index_load(a.get("--index-dir").c_str(), &hx)) error_exit(kr_last_error());
+  kr_index_view view;
+  kr_host_index_view(hx, &view);
+  std::vector<kr_index*> dix(ngpus, nullptr);
+  for (int g = 0; g < ngpus; ++g)
+    if (kr_index_upload(&view, dev0 + g, KR_VIEW_HOST, &dix[g])) error_exit(kr_last_error());
+  fprintf(stderr, "Estimating distances between given sequences and references...\n");
+  auto t0 = std::chrono::steady_clock::now();
+  // header (src/krepp.cpp:311-319)
+  fprintf(out, "# software: krepp\tversion: " KREPP_VERSION "\tinvocation :%s\nSEQ_ID\tREFERENCE_NAME\tDIST\n",
+          invocation.c_str());
+
+  const uint32_t max_reads = 1u << 16;
+  const uint64_t batch_bases = (uint64_t)max_reads * 150, max_bases = batch_bases * 4;
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::deque<Job*> todo;
+  std::map<uint64_t, Job*> finished;
+  bool eof = false;
+  uint64_t total_batches = 0;
+  std::string worker_err;
+
+  auto worker = [&](int g) {
+    kr_stream* st = nullptr;
+    if (kr_stream_create(dix[g], &p, max_reads, max_bases, 0, &st)) {
+      std::lock_guard<std::mutex> lk(mu);
+      worker_err = kr_last_error();
+      cv_done.notify_all();
+      return;
+    }
+    for (;;) {
+      Job* j = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_work.wait(lk, [&] { return !todo.empty() || eof; });
+        if (todo.empty()) break;
+        j = todo.front();
+        todo.pop_front();
+      }
+      cv_work.notify_all(); // the reader may be waiting for queue space
+      std::vector<const char*> nm(j->names.size());
+      for (size_t i = 0; i < nm.size(); ++i) nm[i] = j->names[i].c_str();
+      kr_result_view rv;
+      char* txt = nullptr;
+      uint64_t len = 0;
+      int rc = kr_batch_submit(st, j->bases.data(), j->offsets.data(), (uint32_t)j->names.size(), KR_BASES_HOST);
+      if (!rc) rc = kr_batch_collect(st, &rv);
+      if (!rc) rc = kr_format_dist(hx, &rv, nm.data(), &txt, &len);
+      std::lock_guard<std::mutex> lk(mu);
+      if (rc) {
+        worker_err = kr_last_error();
+      } else {
+        j->text.assign(txt, len);
+        kr_free(txt);
+      }
+      j->done = true;
+      finished[j->seq] = j;
+      cv_done.notify_all();
+    }
+    kr_stream_destroy(st);
+  };
+  std::vector<std::thread> workers;
+  for (int g = 0; g < ngpus; ++g) workers.emplace_back(worker, g);
+
+  std::thread writer([&] {
+    uint64_t next = 0;
+    for (;;) {
+      Job* j = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return finished.count(next) || (eof && next >= total_batches) || !worker_err.empty(); });
+        if (!worker_err.empty()) return;
+        auto it = finished.find(next);
+        if (it == finished.end()) return;
+        j = it->second;
+        finished.erase(it);
+      }
+      fwrite(j->text.data(), 1, j->text.size(), out);
+      delete j;
+      ++next;
+      cv_work.notify_all();
+    }
+  });
+
+  kr_fastx* fx = nullptr;
+  if (kr_fastx_open(a.get("--query").c_str(), &fx)) error_exit(kr_last_error());
+  uint64_t nbatches = 0, nreads_total = 0;
+  for (;;) {
+    kr_fastx_batch b;
+    if (kr_fastx_next(fx, batch_bases, &b)) error_exit(kr_last_error());
+    // split over-long batches so that they fit the stream limits
+    uint32_t r0 = 0;
+    while (r0 < b.nreads) {
+      uint32_t r1 = r0;
+      while (r1 < b.nreads && r1 - r0 < max_reads && b.offsets[r1 + 1] - b.offsets[r0] <= max_bases) ++r1;
+      if (r1 == r0) error_exit("A query sequence is longer than the supported maximum per batch");
+      Job* j = new Job();
+      j->bases.assign(b.bases + b.offsets[r0], b.bases + b.offsets[r1]);
+      j->offsets.resize(r1 - r0 + 1);
+      for (uint32_t i = r0; i <= r1; ++i) j->offsets[i - r0] = b.offsets[i] - b.offsets[r0];
+      for (uint32_t i = r0; i < r1; ++i) j->names.emplace_back(b.names[i]);
+      nreads_total += r1 - r0;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        j->seq = nbatches++;
+        // bound the number of batches in flight
+        cv_work.wait(lk, [&] { return todo.size() < (size_t)(2 * ngpus) || !worker_err.empty(); });
+        todo.push_back(j);
+      }
+      cv_work.notify_all();
+      r0 = r1;
+    }
+    if (!b.more) break;
+  }
+  kr_fastx_close(fx);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    eof = true;
+    total_batches = nbatches;
+  }
+  cv_work.notify_all();
+  cv_done.notify_all();
+  for (auto& w : workers) w.join();
+  cv_done.notify_all();
+  writer.join();
+  if (!worker_err.empty()) error_exit(worker_err);
+  if (out != stdout) fclose(out);
+  for (auto* d : dix) kr_index_free(d);
+  kr_host_index_free(hx);
+  double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  fprintf(stderr, "Done estimating distances, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n", sec,
+          sec > 0 ? nreads_total / sec : 0.0, ngpus);
+  fprintf(stderr, "Total number of sequences queried: %llu\n", (unsigned long long)nreads_total);
+  return 0;
+}
+
+static int run_index(const Args& a)
+{
+  // the reference's `index` takes -i,--input-file (name<TAB>path map) and -o,--index-dir
+  // (src/krepp.cpp:563-566); the shared short-option table maps -i/-o to the dist names.
+  std::string input, outdir;
+  if (a.has("--input-file")) {
+    input = a.get("--input-file");
+    outdir = a.has("--index-dir") ? a.get("--index-dir") : a.get("--output-path");
+  } else {
+    input = a.get("--index-dir");
+    outdir = a.get("--output-path");
+  }
+  if (input.empty() || outdir.empty()) error_exit("index requires -i/--input-file and -o/--index-dir");
+  kr_build_params bp;
+  memset(&bp, 0, sizeof(bp));
+  bp.k = 29, bp.w = 35, bp.h = 13, bp.m = 4, bp.r = 1, bp.frac = 1; // src/krepp.hpp:47-58
+  if (a.has("--kmer-len")) bp.k = (uint32_t)atoi(a.get("--kmer-len").c_str());
+  bool w_given = a.has("--win-len");
+  if (w_given) bp.w = (uint32_t)atoi(a.get("--win-len").c_str());
+  if (a.has("--num-positions")) bp.h = (uint32_t)atoi(a.get("--num-positions").c_str());
+  if (!w_given) { // src/krepp.cpp:579-582
+    bp.w = bp.k + 6;
+    if (!a.has("--num-positions")) bp.h = bp.k - 16;
+  }
+  if (a.has("--modulo-lsh")) bp.m = (uint32_t)atoi(a.get("--modulo-lsh").c_str());
+  if (a.has("--residue-lsh")) bp.r = (uint32_t)atoi(a.get("--residue-lsh").c_str());
+  if (a.flag.count("--frac")) bp.frac = a.flag.at("--frac");
+  bp.num_threads = a.has("--num-threads") ? (uint32_t)atoi(a.get("--num-threads").c_str()) : 1;
+  bp.seed = a.has("--seed") ? (uint32_t)atoi(a.get("--seed").c_str()) : 0;
+  fprintf(stderr, "Building the index...\n");
+  std::string nwk = a.get("--nwk-file");
+  if (kr_build_index(input.c_str(), nwk.empty() ? nullptr : nwk.c_str(), outdir.c_str(), &bp)) error_exit(kr_last_error());
+  fprintf(stderr, "Done converting & saving\n");
+  return 0;
+}
+
+int main(int argc, char** argv)
+{
+  fprintf(stderr, "krepp version: " KREPP_VERSION " (krepp-amd, MI355X)\n"); // PRINT_VERSION, src/common.hpp:51
+  Args a = parse(argc, argv);
+  std::string invocation;
+  for (int i = 0; i < argc; ++i) invocation += std::string(argv[i]) + (i + 1 < argc ? " " : "");
+  std::time_t now = std::time(nullptr);
+  fprintf(stderr, "Invocation: %s\n%s", invocation.c_str(), std::ctime(&now));
+  int rc;
+  if (a.sub == "dist")
+    rc = run_dist(a, invocation);
+  else if (a.sub == "index")
+    rc = run_index(a);
+  else if (a.sub == "place" || a.sub == "seek" || a.sub == "sketch" || a.sub == "inspect")
+    error_exit("sub-command `" + a.sub + "` is outside the scope of this build (dist/index only)");
+  else
+    error_exit("A subcommand is required (dist | index)");
+  now = std::time(nullptr);
+  fprintf(stderr, "%s", std::ctime(&now));
+  return rc;
+}

@@ -154,15 +154,16 @@ def sample_reads(genomes, nreads, seed, length=150, n_frac=0.01, mix=DIVERGENCE_
     allg = np.concatenate(gl)
     gstart = np.concatenate([[0], np.cumsum(glen)[:-1]])
     idx = (gstart[gi] + off)[:, None] + np.arange(length)[None, :]
-    reads = allg[idx]  # (nreads, length) uint8 ASCII
-    codes = np.searchsorted(BASES, reads).astype(np.uint8)
-    # substitutions
-    mut = rng.uniform(nreads * length).reshape(nreads, length) < np.where(rates >= 0, rates, 0.0)[:, None]
-    shift = (1 + rng.below(nreads * length, 3)).astype(np.uint8).reshape(nreads, length)
+    codes = np.searchsorted(BASES, allg[idx]).astype(np.uint8)  # (nreads, length) 2-bit codes
+    # one 64-bit draw per base: bits 63..32 decide the substitution, 9..8 the new base offset,
+    # 1..0 the base of an unrelated read
+    x = rng.u64(nreads * length).reshape(nreads, length)
+    thr = (np.where(rates >= 0, rates, 0.0) * 4294967296.0).astype(np.uint64)
+    mut = (x >> np.uint64(32)) < thr[:, None]
+    shift = (((x >> np.uint64(8)) & np.uint64(0xFFFF)) % np.uint64(3)).astype(np.uint8) + np.uint8(1)
     codes = np.where(mut, (codes + shift) & 3, codes)
     unrelated = rates < 0
-    rnd = rng.below(nreads * length, 4).astype(np.uint8).reshape(nreads, length)
-    codes = np.where(unrelated[:, None], rnd, codes)
+    codes = np.where(unrelated[:, None], (x & np.uint64(3)).astype(np.uint8), codes)
     reads = BASES[codes]
     # reverse complement
     rc = COMP[reads[:, ::-1]]

@@ -1,0 +1,314 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the oracle.
+Bar: bit-exact for rix/enc32/table hits/histograms/row sets; DIST within 1e-6 relative
+(north star) — in practice ~1e-11 (device vs glibc pow/log)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_rows_close, rows_of_oracle
+from helpers import closed_form, hd32, revcomp, row_of, write_index
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def toy(capi, po, toy_index_dir):
+    hx = capi.HostIndex(toy_index_dir)
+    dx = hx.upload(0)
+    return hx, dx, po.Index(toy_index_dir)
+
+
+def gpu_dist(capi, dx, bases, offs, flags=0, **pkw):
+    st = dx.stream(params=capi.default_params(**pkw), max_reads=len(offs) - 1, max_bases=max(1, len(bases)))
+    st.submit(bases, offs, flags)
+    res = st.collect()
+    return st, res
+
+
+def test_front_end_bit_exact(capi, toy, toy_reads):
+    hx, dx, ox = toy
+    names, bases, offs = toy_reads
+    lens = np.diff(offs).astype(int)
+    stride = int(lens.max()) - 21 + 1
+    rix, enc, valid, pas = dx.front_end(bases, offs, stride)
+    for r in range(len(names)):
+        fe = ox.front_end(bytes(bases[int(offs[r]):int(offs[r + 1])]))
+        seen = np.zeros((stride, 2), bool)
+        for i in range(len(fe["kpos"])):
+            kp, s = int(fe["kpos"][i]), int(fe["strand"][i])
+            assert valid[r, kp, s] == 1, (names[r], kp, s)
+            assert rix[r, kp, s] == fe["rix"][i] and enc[r, kp, s] == fe["enc32"][i] and pas[r, kp, s] == fe["pas"][i]
+            seen[kp, s] = True
+        assert not valid[r][~seen].any(), names[r]  # windows with N / past the end are invalid
+
+
+def test_hits_accumulators_rows_match_committed_golden(capi, toy, toy_reads):
+    hx, dx, ox = toy
+    names, bases, offs = toy_reads
+    exp = json.load(open(os.path.join(GOLDEN, "toy_expected.json")))["default"]
+    st, res = gpu_dist(capi, dx, bases, offs, capi.KR_TAP_ACCS | capi.KR_TAP_HITS)
+    assert len(st.hits()) == exp["nhits"]
+    assert res.read_onmers.tolist() == exp["onmers"]
+    assert st.readtaps(len(names)).tolist() == exp["hdist_filt"]
+    want_acc = sorted((a[0], (a[1] << 1) | a[2], tuple(a[4])) for a in exp["accs"] if a[3])
+    got_acc = sorted(zip(res.rec_read.tolist(), res.rec_key.tolist(), [tuple(x) for x in res.rec_hist.tolist()]))
+    assert got_acc == want_acc
+    want = sorted((r, s, float.fromhex(d)) for r, s, d in exp["rows"] if s != 0)
+    assert_rows_close(res.rows(), want)
+    assert sorted(st.format_dist(hx, names).splitlines()) == sorted(exp["text"].splitlines())
+
+
+@pytest.mark.parametrize("tag,pkw", [("filter", dict(no_filter=0)), ("nomulti", dict(multi=0)),
+                                     ("dmax", dict(dist_max=0.05)), ("th2", dict(hdist_th=2))])
+def test_report_modes_match_golden(capi, toy, toy_reads, tag, pkw):
+    hx, dx, ox = toy
+    names, bases, offs = toy_reads
+    exp = json.load(open(os.path.join(GOLDEN, "toy_expected.json")))[tag]
+    st, res = gpu_dist(capi, dx, bases, offs, 0, **pkw)
+    want = sorted((r, s, float.fromhex(d)) for r, s, d in exp["rows"] if s != 0)
+    assert_rows_close(res.rows(), want)
+    assert sorted(st.format_dist(hx, names).splitlines()) == sorted(exp["text"].splitlines())
+
+
+def test_hits_bit_exact_vs_oracle(capi, po, toy, toy_genomes, synth):
+    hx, dx, ox = toy
+    bases, offs, names = synth.sample_reads(toy_genomes, 3000, seed=11)
+    ref = ox.dist(bases, offs, names, po.params(collect=7))
+    st, res = gpu_dist(capi, dx, bases, offs, capi.KR_TAP_ACCS | capi.KR_TAP_HITS)
+    gh, rh = st.hits(), ref["hits"]
+    key = lambda h: sorted(zip(h["read"].tolist(), h["strand"].tolist(), h["kpos"].tolist(), h["cmer_index"].tolist(),
+                               h["hd"].tolist(), h["se"].tolist()))
+    assert key(gh) == key(rh)
+    acc = ref["accs"][ref["accs"]["passed"] == 1]
+    want = sorted(zip(acc["read"].tolist(), ((acc["se"] << 1) | acc["strand"]).tolist(), [tuple(x[:5]) for x in acc["hist"].tolist()]))
+    got = sorted(zip(res.rec_read.tolist(), res.rec_key.tolist(), [tuple(x) for x in res.rec_hist.tolist()]))
+    assert got == want
+    assert_rows_close(res.rows(), rows_of_oracle(ref))
+    assert sorted(st.format_dist(hx, names).splitlines()) == sorted(ref["text"].splitlines())
+    # determinism: a second run returns identical bytes per read
+    st2, res2 = gpu_dist(capi, dx, bases, offs, capi.KR_TAP_ACCS)
+    a = sorted(zip(res.rec_read.tolist(), res.rec_key.tolist(), res.rec_d.tolist(), res.rec_sel.tolist()))
+    b = sorted(zip(res2.rec_read.tolist(), res2.rec_key.tolist(), res2.rec_d.tolist(), res2.rec_sel.tolist()))
+    assert a == b
+
+
+@pytest.mark.parametrize("k,w,h,m,r,frac", [(27, 35, 11, 4, 1, True), (29, 35, 13, 64, 3, False), (19, 19, 3, 2, 0, True),
+                                            (31, 40, 15, 8, 5, True)])
+def test_other_index_shapes(capi, po, synth, tmp_path, k, w, h, m, r, frac):
+    nwk_path = os.path.join(GOLDEN, "tree_toy.nwk")
+    g = synth.evolve_genomes(open(nwk_path).read(), 30000, seed=5)
+    tsv = synth.write_genomes(g, str(tmp_path / "g"))
+    idx = str(tmp_path / "ix")
+    capi.build_index(tsv, idx, nwk=nwk_path, k=k, w=w, h=h, m=m, r=r, frac=frac, num_threads=4)
+    hx = capi.HostIndex(idx)
+    dx = hx.upload(0)
+    ox = po.Index(idx)
+    bases, offs, names = synth.sample_reads(g, 1500, seed=2)
+    ref = ox.dist(bases, offs, names, po.params(collect=7))
+    st, res = gpu_dist(capi, dx, bases, offs, capi.KR_TAP_ACCS | capi.KR_TAP_HITS)
+    assert len(st.hits()) == len(ref["hits"])
+    assert res.read_onmers.tolist() == ref["reads"]["onmers"].tolist()
+    assert_rows_close(res.rows(), rows_of_oracle(ref))
+    assert sorted(st.format_dist(hx, names).splitlines()) == sorted(ref["text"].splitlines())
+
+
+def test_reflist_only_index_and_two_libraries(capi, po, synth, tmp_path):
+    g = synth.evolve_genomes("((a:0.02,b:0.02):0.02,(c:0.03,(d:0.01,e:0.01):0.02):0.01);", 20000, seed=9)
+    tsv = synth.write_genomes(g, str(tmp_path / "g"))
+    idx = str(tmp_path / "ix")
+    pp = [20, 19, 17, 13, 6, 4, 2]
+    # two partial libraries (no_frac r=0 and r=2), no tree: reflist + generated balanced tree
+    capi.build_index(tsv, idx, k=21, w=27, h=7, m=4, r=0, frac=False, ppos=pp)
+    capi.build_index(tsv, idx, k=21, w=27, h=7, m=4, r=2, frac=False, ppos=pp)
+    hx = capi.HostIndex(idx)
+    assert hx.view.nlibs == 2 and hx.view.wbackbone == 0
+    dx = hx.upload(0)
+    ox = po.Index(idx)
+    bases, offs, names = synth.sample_reads(g, 1000, seed=4)
+    ref = ox.dist(bases, offs, names, po.params(collect=7))
+    st, res = gpu_dist(capi, dx, bases, offs, capi.KR_TAP_HITS)
+    gh, rh = st.hits(), ref["hits"]
+    key = lambda h_: sorted(zip(h_["read"].tolist(), h_["strand"].tolist(), h_["kpos"].tolist(), h_["lib"].tolist(),
+                                h_["cmer_index"].tolist(), h_["hd"].tolist()))
+    assert key(gh) == key(rh)
+    assert_rows_close(res.rows(), rows_of_oracle(ref))
+    assert sorted(st.format_dist(hx, names).splitlines()) == sorted(ref["text"].splitlines())
+
+
+def test_crafted_min_rule_null_nodes_and_th(capi, po, tmp_path):
+    """Crafted table: two entries in one bucket reaching the same leaf with different hd (the
+    per-position minimum must win), an entry whose colour is the empty set, hd above the
+    threshold, and a colour id beyond nsubsets."""
+    PPOS = [20, 19, 17, 13, 6, 4, 2]
+    NPOS = [p for p in range(21) if p not in PPOS]
+    rng = np.random.default_rng(17)
+    while True:
+        s = "".join("ACGT"[i] for i in rng.integers(0, 4, 60))
+        rows, ok = {}, True
+        for i in range(0, 40):
+            km = s[i:i + 21]
+            f = closed_form(km, PPOS, NPOS)
+            row = row_of(f[2], 4, 1, True)
+            if row is None:
+                continue
+            ents = rows.setdefault(row, [])
+            ents.append((f[3], 6))                       # hd 0 -> {x,z}
+            ents.append((f[3] ^ (1 << 2), 8))            # hd 1 -> {x,z,y}
+            ents.append((f[3] ^ 0b11, 0))                # hd 2 -> empty colour
+            ents.append((f[3] ^ 0b11111100000, 1))       # hd 6 > th
+            ents.append((f[3] ^ (1 << 5), 99))           # hd 1, colour id out of range -> dropped
+        if all(len({e for e, _ in v}) == len(v) for v in rows.values()):
+            break
+    pse = [(0, 0), (0, 1), (0, 2), (1, 2), (0, 4), (3, 4), (1, 4), (2, 0), (6, 2)]
+    rho = [0.0, 0.2, 0.25, 0.0, 0.3, 0.0]
+    d = str(tmp_path / "ix")
+    write_index(d, 21, 7, 4, 1, True, PPOS, rows, pse, rho, nwk="((x:0.1,y:0.1)n1:0.1,z:0.2);")
+    hx = capi.HostIndex(d)
+    dx = hx.upload(0)
+    ox = po.Index(d)
+    reads = [s, revcomp(s), s[:21], s[5:50].lower(), s[:30] + "N" + s[31:]]
+    bases = np.frombuffer("".join(reads).encode(), np.uint8)
+    offs = np.cumsum([0] + [len(x) for x in reads]).astype(np.uint64)
+    for th in (0, 1, 4, 6, 16):
+        ref = ox.dist(bases, offs, None, po.params(collect=7, hdist_th=th))
+        st, res = gpu_dist(capi, dx, bases, offs, capi.KR_TAP_ACCS | capi.KR_TAP_HITS, hdist_th=th)
+        assert len(st.hits()) == len(ref["hits"]) > 0
+        acc = ref["accs"][ref["accs"]["passed"] == 1]
+        want = sorted(zip(acc["read"].tolist(), ((acc["se"] << 1) | acc["strand"]).tolist(), [tuple(x[:th + 1]) for x in acc["hist"].tolist()]))
+        got = sorted(zip(res.rec_read.tolist(), res.rec_key.tolist(), [tuple(x) for x in res.rec_hist.tolist()]))
+        assert got == want, th
+        assert_rows_close(res.rows(), rows_of_oracle(ref))
+        assert st.readtaps(len(reads)).tolist() == ref["reads"]["hdist_filt"].tolist()
+
+
+def test_long_reads_and_ragged_batches(capi, po, toy, toy_genomes):
+    """Multi-segment reads (> 128 k-mer positions), empty reads, reads shorter than k."""
+    hx, dx, ox = toy
+    g = toy_genomes
+    rng = np.random.default_rng(23)
+    seqs = []
+    for L in (0, 1, 20, 21, 22, 148, 149, 150, 151, 170, 300, 1000, 5000, 19999):
+        name = list(g)[int(rng.integers(0, 25))]
+        o = int(rng.integers(0, 20000 - L + 1))
+        s = bytearray(g[name][o:o + L].tobytes())
+        for _ in range(L // 50):  # a few substitutions and the odd N
+            s[int(rng.integers(0, L))] = b"ACGTN"[int(rng.integers(0, 5))]
+        seqs.append(bytes(s))
+    bases = np.frombuffer(b"".join(seqs), np.uint8)
+    offs = np.cumsum([0] + [len(s) for s in seqs]).astype(np.uint64)
+    names = [f"L{len(s)}" for s in seqs]
+    ref = ox.dist(bases, offs, names, po.params(collect=7))
+    st, res = gpu_dist(capi, dx, bases, offs, capi.KR_TAP_ACCS | capi.KR_TAP_HITS)
+    assert res.read_onmers.tolist() == ref["reads"]["onmers"].tolist()
+    gh, rh = st.hits(), ref["hits"]
+    key = lambda h_: sorted(zip(h_["read"].tolist(), h_["strand"].tolist(), h_["kpos"].tolist(), h_["cmer_index"].tolist(), h_["hd"].tolist()))
+    assert key(gh) == key(rh)
+    acc = ref["accs"][ref["accs"]["passed"] == 1]
+    want = sorted(zip(acc["read"].tolist(), ((acc["se"] << 1) | acc["strand"]).tolist(), [tuple(x[:5]) for x in acc["hist"].tolist()]))
+    got = sorted(zip(res.rec_read.tolist(), res.rec_key.tolist(), [tuple(x) for x in res.rec_hist.tolist()]))
+    assert got == want
+    assert_rows_close(res.rows(), rows_of_oracle(ref))
+    assert sorted(st.format_dist(hx, names).splitlines()) == sorted(ref["text"].splitlines())
+
+
+def test_overflow_path_many_leaves(capi, po, synth, tmp_path):
+    """Reads that reach more (strand, leaf) pairs than the LDS table holds take the
+    global-memory accumulator path; results must not change."""
+    n = 96
+    names = [f"s{i}" for i in range(n)]
+    # star-ish tree of close relatives: every read matches nearly every genome
+    nwk = "(" + ",".join(f"{x}:0.004" for x in names) + ");"
+    g = synth.evolve_genomes(nwk, 6000, seed=13)
+    tsv = synth.write_genomes(g, str(tmp_path / "g"))
+    (tmp_path / "t.nwk").write_text(nwk)
+    idx = str(tmp_path / "ix")
+    capi.build_index(tsv, idx, nwk=str(tmp_path / "t.nwk"), k=21, w=27, h=7, m=4, r=1, frac=True, num_threads=4,
+                     ppos=[20, 19, 17, 13, 6, 4, 2])
+    hx = capi.HostIndex(idx)
+    dx = hx.upload(0)
+    ox = po.Index(idx)
+    bases, offs, rn = synth.sample_reads(g, 400, seed=6)
+    ref = ox.dist(bases, offs, rn, po.params(collect=7))
+    st = dx.stream(max_reads=400, max_bases=len(bases), max_records=400 * 2 * n)
+    st.submit(bases, offs, capi.KR_TAP_ACCS)
+    res = st.collect()
+    assert st.timing().overflow_reads > 50
+    acc = ref["accs"][ref["accs"]["passed"] == 1]
+    want = sorted(zip(acc["read"].tolist(), ((acc["se"] << 1) | acc["strand"]).tolist(), [tuple(x[:5]) for x in acc["hist"].tolist()]))
+    got = sorted(zip(res.rec_read.tolist(), res.rec_key.tolist(), [tuple(x) for x in res.rec_hist.tolist()]))
+    assert got == want
+    assert_rows_close(res.rows(), rows_of_oracle(ref))
+    # default record capacity is too small here: the library must say so, not truncate
+    st2 = dx.stream(max_reads=400, max_bases=len(bases), max_records=1000)
+    st2.submit(bases, offs)
+    with pytest.raises(capi.KrError) as e:
+        st2.collect()
+    assert e.value.code == capi.KR_ERR_CAPACITY
+
+
+def test_device_brent_vs_oracle(capi, po, toy):
+    hx, dx, ox = toy
+    rng = np.random.default_rng(31)
+    n = 20000
+    hist = np.floor(rng.random((n, 5)) ** 3 * rng.integers(1, 125, (n, 1))).astype(np.uint32)
+    hist[hist.sum(1) == 0, 0] = 1
+    tot = hist.sum(1)
+    onm = (tot + rng.integers(0, 60, n)).astype(np.uint32)
+    rho = rng.uniform(0.02, 0.6, n)
+    d, v = dx.brent(4, hist, onm, rho)
+    bad = 0
+    for i in range(n):
+        od, ov, _ = po.brent(21, 7, 4, hist[i].astype(float), float(onm[i]) - float(tot[i]), float(rho[i]))
+        assert abs(d[i] - od) <= 1e-6 * od, (i, d[i], od)
+        bad += d[i] != od
+    # identical Brent trajectories: differences are only pow/log rounding (~1e-11 relative)
+    assert np.all(np.isfinite(v))
+
+
+def test_large_batch_properties(capi, toy, toy_genomes, synth):
+    """Size-independent properties on a batch far larger than the oracle is run on:
+    (1) reverse-complementing every read leaves the (read, leaf, DIST) rows unchanged;
+    (2) permuting the reads permutes the results; (3) splitting the batch changes nothing."""
+    hx, dx, ox = toy
+    bases, offs, _ = synth.sample_reads(toy_genomes, 200_000, seed=77)
+    n = len(offs) - 1
+    st, res = gpu_dist(capi, dx, bases, offs)
+    rows = res.rows()
+    assert len(rows) > n  # multi-hit reads dominate
+    rc = synth.COMP[bases.reshape(n, 150)[:, ::-1]].reshape(-1)
+    _, res_rc = gpu_dist(capi, dx, rc, offs)
+    assert res_rc.rows() == rows
+    perm = np.random.default_rng(1).permutation(n)
+    pb = bases.reshape(n, 150)[perm].reshape(-1)
+    _, res_p = gpu_dist(capi, dx, pb, offs)
+    inv = {int(new): int(old) for new, old in enumerate(perm)}
+    assert sorted((inv[r], s, d) for r, s, d in res_p.rows()) == rows
+    half = n // 2
+    _, r1 = gpu_dist(capi, dx, bases[: half * 150], offs[: half + 1])
+    _, r2 = gpu_dist(capi, dx, bases[half * 150:], offs[half:] - offs[half])
+    assert r1.rows() + [(r + half, s, d) for r, s, d in r2.rows()] == rows
+
+
+def test_index_export_import_roundtrip(capi, toy, toy_reads):
+    """The replication path used for multi-GPU: export flat buffers, import on a device,
+    copy the bytes, query the replica."""
+    import torch
+    hx, dx, ox = toy
+    names, bases, offs = toy_reads
+    desc, bufs = dx.export()
+    dx2, bufs2 = capi.DeviceIndex.import_empty(desc, 0)
+    assert [b for _, b in bufs] == [b for _, b in bufs2]
+
+    class DevPtr:
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+    for (p1, nb), (p2, _) in zip(bufs, bufs2):
+        if nb:
+            torch.as_tensor(DevPtr(p2, nb), device="cuda:0").copy_(torch.as_tensor(DevPtr(p1, nb), device="cuda:0"))
+    torch.cuda.synchronize()
+    _, a = gpu_dist(capi, dx, bases, offs)
+    _, b = gpu_dist(capi, dx2, bases, offs)
+    assert a.rows() == b.rows() and len(a.rows()) > 100
