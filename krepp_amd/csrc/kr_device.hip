@@ -54,7 +54,7 @@ constexpr int kSegPos = 128;      // k-mer positions per segment = 4 plane words
 constexpr int kPlaneWords = kSegPos / 32;
 constexpr int kMaxRuns = 16;
 constexpr int kMaxLibs = 16;
-constexpr int kStackCap = 512;    // colour work stack (items of 8 B)
+constexpr int kStackCap = 256;    // colour work stack (items of 8 B)
 constexpr int kLdsSlots = 64;     // LDS accumulator table entries per wave
 constexpr int kMaxPlanes = KR_MAX_HDIST_TH + 1;
 
@@ -80,6 +80,8 @@ struct DevIndex {
   const uint8_t* kind;   // [tree_nnodes+1] 0 null, 1 leaf, 2 internal
   const int32_t* res_lib; // [m] library serving each residue, or -1
   const DevLib* libs;    // [nlibs] in device memory
+  uint64_t res_mask;     // nlibs == 1 && m <= 64: bit r set iff residue r is served
+  DevLib lib0;           // copy of libs[0]: single-library indexes never touch `libs`
 };
 
 struct LlhConst {
@@ -236,11 +238,20 @@ __device__ __forceinline__ bool locate_row(const DevIndex& ix, uint32_t rix, int
     q = rix / ix.m;
     res = rix - q * ix.m;
   }
-  lib = ix.res_lib[res];
-  if (lib < 0) return false;
-  uint32_t numer = ix.libs[lib].numer;
+  uint32_t numer, nrows;
+  if (ix.nlibs == 1 && ix.m <= 64) { // everything from kernel arguments
+    if (!((ix.res_mask >> res) & 1ull)) return false;
+    lib = 0;
+    numer = ix.lib0.numer;
+    nrows = ix.lib0.nrows;
+  } else {
+    lib = ix.res_lib[res];
+    if (lib < 0) return false;
+    numer = ix.libs[lib].numer;
+    nrows = ix.libs[lib].nrows;
+  }
   row = numer > 1 ? q * numer + res : q;
-  return row < ix.libs[lib].nrows;
+  return row < nrows;
 }
 
 // ---------------------------------------------------------------------------
@@ -252,9 +263,9 @@ struct Table {
   uint32_t* keys;
   uint32_t* planes;
   uint32_t* counts;
-  uint32_t* touched; // GT only
+  uint32_t* touched;  // GT only
   uint32_t* ntouched; // GT only (LDS word)
-  uint32_t mask;     // slots - 1
+  uint32_t mask;      // slots - 1
   uint32_t np;
 
   __device__ __forceinline__ uint32_t load_key(uint32_t s) const
@@ -334,38 +345,83 @@ struct Table {
     else
       keys[s] = v;
   }
+  // smallest x with a non-zero count, or 0xFFFFFFFF
+  __device__ __forceinline__ uint32_t hdist_min(uint32_t s) const
+  {
+    for (uint32_t x = 0; x < np; ++x)
+      if (load_count(s * np + x)) return x;
+    return 0xFFFFFFFFu;
+  }
 };
 
-// tag of a pending colour: position in segment, strand, Hamming distance, library
-__device__ __forceinline__ uint32_t make_tag(uint32_t pos, uint32_t strand, uint32_t hd, uint32_t lib)
-{
-  return pos | (strand << 7) | (hd << 8) | (lib << 13);
-}
+// Work-stack item (8 B).  hi = pos(7) | strand(1)<<7 | lib(4)<<8 | hd(5)<<12 | idx_hi(8)<<17 |
+// unresolved<<31.  Resolved: lo = colour id.  Unresolved (a fresh table hit whose colour has not
+// been fetched yet): lo | idx_hi<<32 = entry index into the library's se[] array.
+constexpr uint32_t kItemUnresolved = 0x80000000u;
+__device__ __forceinline__ uint32_t tag_pos(uint32_t t) { return t & 127u; }
+__device__ __forceinline__ uint32_t tag_strand(uint32_t t) { return (t >> 7) & 1u; }
+__device__ __forceinline__ uint32_t tag_lib(uint32_t t) { return (t >> 8) & 15u; }
+__device__ __forceinline__ uint32_t tag_hd(uint32_t t) { return (t >> 12) & 31u; }
 
 struct WaveState {
-  uint2* stack;       // LDS [kStackCap]
-  uint32_t top;       // wave-uniform
-  bool overflow;      // table full for this read (any lane)
+  uint2* stack;  // LDS [kStackCap]
+  uint32_t top;  // wave-uniform
+  bool overflow; // table full for this read (any lane)
   uint32_t err;
+  uint32_t read;   // for the hit tap
+  uint32_t base0;  // first k-mer position of the current segment
 };
+
+__device__ __forceinline__ DevLib get_lib(const DevIndex& ix, uint32_t lib)
+{
+  if (ix.nlibs == 1) return ix.lib0; // kernel-argument (SGPR) copy: no dependent load
+  return ix.libs[lib];
+}
+
+// zero the whole LDS table (kernel start, and after a read that overflowed it)
+__device__ __forceinline__ void clear_lds_table(const Table<false>& tb)
+{
+  for (uint32_t s = lane_id(); s <= tb.mask; s += 64) {
+    tb.keys[s] = 0;
+    for (uint32_t x = 0; x < tb.np; ++x) {
+      tb.counts[s * tb.np + x] = 0;
+#pragma unroll
+      for (int w = 0; w < kPlaneWords; ++w) tb.planes[(s * tb.np + x) * kPlaneWords + w] = 0;
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void clear_lds_table(const Table<true>&) {}
 
 template <bool GT>
 __device__ __forceinline__ void accumulate(const Table<GT>& tb, WaveState& ws, uint32_t se, uint32_t tag)
 {
-  uint32_t key = (se << 1) | ((tag >> 7) & 1u);
+  uint32_t key = (se << 1) | tag_strand(tag);
   int slot = tb.find_or_insert(key);
   if (slot < 0) {
     ws.overflow = true;
     return;
   }
-  tb.or_bit(slot, (tag >> 8) & 31u, tag & 127u);
+  tb.or_bit(slot, tag_hd(tag), tag_pos(tag));
 }
 
-// Colour expansion (the BFS of src/query.cpp:369-387, order-free here): drain the work
-// stack; tree leaves go to the accumulator, null nodes are dropped, everything else is
-// replaced by the two halves of se_to_pse[se].
+// classify one colour: leaf -> accumulate, null -> drop, anything else -> caller pushes it
 template <bool GT>
-__device__ __forceinline__ void expand_all(const DevIndex& ix, const Table<GT>& tb, WaveState& ws)
+__device__ __forceinline__ bool colour_needs_expansion(const DevIndex& ix, const Table<GT>& tb, WaveState& ws,
+                                                       uint32_t se, uint32_t tag)
+{
+  if (se == 0) return false;
+  if (se <= ix.tree_nnodes) { // Tree::check_node (src/phytree.hpp:34)
+    uint32_t kd = ix.kind[se];
+    if (kd == 1) accumulate(tb, ws, se, tag);
+    return kd == 2;
+  }
+  return true;
+}
+
+// Colour expansion (the BFS of src/query.cpp:369-387, order-free here): drain the work stack.
+template <bool GT, bool TAP>
+__device__ __forceinline__ void expand_all(const DevIndex& ix, const BatchOut& out, const Table<GT>& tb, WaveState& ws)
 {
   const uint32_t lane = lane_id();
   while (ws.top > 0) {
@@ -381,45 +437,47 @@ __device__ __forceinline__ void expand_all(const DevIndex& ix, const Table<GT>& 
     uint2 item = have ? ws.stack[base + lane] : make_uint2(0, 0);
     ws.top = base;
     uint32_t se = item.x, tag = item.y;
-    uint32_t child[2] = {0, 0};
-    bool push[2] = {false, false};
-    if (have && se != 0) {
-      bool expand = true;
-      if (se <= ix.tree_nnodes) { // Tree::check_node (src/phytree.hpp:34)
-        uint32_t kd = ix.kind[se];
-        expand = kd == 2;
-        if (kd == 1) accumulate(tb, ws, se, tag);
-      }
-      if (expand) {
-        const DevLib& L = ix.libs[(tag >> 13) & 15u];
-        uint2 pr = se < L.nsubsets ? L.pse[se] : make_uint2(0, 0);
-        child[0] = pr.x;
-        child[1] = pr.y;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          uint32_t cs = child[c];
-          if (cs == 0) continue;
-          if (cs <= ix.tree_nnodes) {
-            uint32_t kd = ix.kind[cs];
-            if (kd == 1)
-              accumulate(tb, ws, cs, tag);
-            else if (kd == 2)
-              push[c] = true;
+    uint32_t c0 = 0, c1 = 0;
+    bool p0 = false, p1 = false;
+    if (have) {
+      DevLib L = get_lib(ix, tag_lib(tag));
+      bool expand;
+      if (tag & kItemUnresolved) { // fetch the colour of a fresh hit
+        uint64_t idx = (uint64_t)item.x | ((uint64_t)((tag >> 17) & 0xFFu) << 32);
+        se = L.se[idx];
+        if (TAP) {
+          uint32_t hix = atomicAdd(&out.counters[3], 1u);
+          if (hix < out.hit_cap) {
+            kr_hit h;
+            h.read = ws.read;
+            h.kpos = ws.base0 + tag_pos(tag);
+            h.strand = tag_strand(tag);
+            h.lib = tag_lib(tag);
+            h.cmer_index = idx;
+            h.hd = tag_hd(tag);
+            h.se = se;
+            out.hits[hix] = h;
           } else {
-            push[c] = true;
+            atomicOr(&out.counters[1], kErrHitCap);
           }
         }
+        tag &= 0x1FFFFu;
+      }
+      expand = colour_needs_expansion(ix, tb, ws, se, tag);
+      if (expand) {
+        uint2 pr = se < L.nsubsets ? L.pse[se] : make_uint2(0, 0);
+        c0 = pr.x;
+        c1 = pr.y;
+        p0 = colour_needs_expansion(ix, tb, ws, c0, tag);
+        p1 = colour_needs_expansion(ix, tb, ws, c1, tag);
       }
     }
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      uint64_t m = __ballot(push[c]);
-      if (push[c]) {
-        uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
-        ws.stack[ws.top + off] = make_uint2(child[c], tag);
-      }
-      ws.top += __popcll(m);
-    }
+    uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
+    uint64_t lt = (1ull << lane) - 1ull;
+    if (p0) ws.stack[ws.top + __popcll(m0 & lt)] = make_uint2(c0, tag);
+    ws.top += __popcll(m0);
+    if (p1) ws.stack[ws.top + __popcll(m1 & lt)] = make_uint2(c1, tag);
+    ws.top += __popcll(m1);
     __syncthreads();
   }
 }
@@ -427,13 +485,61 @@ __device__ __forceinline__ void expand_all(const DevIndex& ix, const Table<GT>& 
 // ---------------------------------------------------------------------------
 // The probe kernel body for one read.
 // ---------------------------------------------------------------------------
+constexpr int kListCap = 128; // probes per group: 64 positions x 2 strands
 struct ProbeList {
-  uint64_t* start;   // [64]
-  uint32_t* len;     // [64]
-  uint32_t* q;       // [64]
-  uint32_t* tag;     // [64] make_tag(pos, strand, 0, lib)
-  uint32_t* pre;     // [65] exclusive prefix of 16-byte chunk counts
+  uint64_t* bkt;  // [128] (start << 24) | len
+  uint32_t* q;    // [128] residual code of the query k-mer
+  uint32_t* tag;  // [128] pos | strand<<7 | lib<<8
+  uint32_t* pre;  // [129] exclusive prefix of 16-byte chunk counts
 };
+
+struct Cand { // one lane's two candidate probes (forward, reverse) of a position
+  uint64_t b[2];
+  uint32_t q[2];
+  uint32_t lib[2];
+};
+
+// front end + descriptor loads for positions 64*pp + lane
+__device__ __forceinline__ Cand fetch_group(const DevIndex& ix, const SegBits& sb, int pp, uint32_t npos_seg,
+                                            uint32_t& nvalid)
+{
+  Cand c;
+  FrontEnd fe = front_end(ix, sb, pp, npos_seg);
+  nvalid = __popcll(__ballot(fe.valid));
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    int lib = -1;
+    uint32_t row = 0;
+    c.b[s] = 0;
+    c.q[s] = fe.enc32[s];
+    c.lib[s] = 0;
+    if (fe.valid && locate_row(ix, fe.rix[s], lib, row)) {
+      c.lib[s] = (uint32_t)lib;
+      c.b[s] = get_lib(ix, (uint32_t)lib).bkt[row];
+    }
+  }
+  return c;
+}
+
+struct ChunkHits {
+  uint64_t e0;      // first entry index of the 16-byte chunk
+  uint32_t tag;     // probe tag
+  uint32_t mask;    // 4-bit hit mask
+  uint32_t hds;     // 4 x 8-bit hd
+};
+
+__device__ __forceinline__ uint32_t find_probe(const ProbeList& pl, uint32_t nact, uint32_t c)
+{ // largest pi with pre[pi] <= c
+  uint32_t lo = 0, hi = nact;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (pl.pre[mid] <= c)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
 
 template <bool GT, bool TAP>
 __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams& P, const BatchIn& in,
@@ -441,189 +547,154 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
                                              WaveState& ws, const ProbeList& pl)
 {
   const uint32_t lane = lane_id();
+  const uint64_t lt = (1ull << lane) - 1ull;
   const uint64_t off0 = in.offsets[read], off1 = in.offsets[read + 1];
   const uint8_t* seq = in.bases + off0;
   const uint64_t len = off1 - off0;
   const uint32_t k = ix.k;
   const uint64_t nkm = len >= k ? len - k + 1 : 0; // enmers (src/query.cpp:42)
   uint32_t onmers = 0;
-  uint32_t filt[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+  uint32_t filt0 = 0xFFFFFFFFu, filt1 = 0xFFFFFFFFu;
   ws.top = 0;
   ws.overflow = false;
-
-  // table starts empty
-  if (!GT) {
-    for (uint32_t s = lane; s <= tb.mask; s += 64) {
-      tb.keys[s] = 0;
-      for (uint32_t x = 0; x < tb.np; ++x) {
-        tb.counts[s * tb.np + x] = 0;
-        for (int w = 0; w < kPlaneWords; ++w) tb.planes[(s * tb.np + x) * kPlaneWords + w] = 0;
-      }
-    }
-  }
-  __syncthreads();
+  ws.read = read;
 
   for (uint64_t base0 = 0; base0 < nkm; base0 += kSegPos) {
     const uint32_t npos_seg = (uint32_t)min((uint64_t)kSegPos, nkm - base0);
+    ws.base0 = (uint32_t)base0;
     SegBits sb;
     load_segment(seq, len, base0, sb);
-    // Four probe rounds per segment (position half pp x strand) plus a fifth, empty round
-    // whose only job is to drain the colour stack; one expand_all call site serves all.
-    FrontEnd fe;
-    fe.valid = false;
-    for (int rnd = 0; rnd < 5; ++rnd) {
-      const int pp = rnd >> 1, strand = rnd & 1;
-      uint32_t total = 0, nact = 0;
-      if (rnd < 4 && 64u * pp < npos_seg) {
-        if (strand == 0) {
-          fe = front_end(ix, sb, pp, npos_seg);
-          onmers += __popcll(__ballot(fe.valid));
-        }
-        // ---- bucket lookup for this lane's probe
-        int lib = -1;
-        uint32_t row = 0, blen = 0;
-        uint64_t bstart = 0;
-        if (fe.valid && locate_row(ix, fe.rix[strand], lib, row)) {
-          uint64_t b = ix.libs[lib].bkt[row];
-          bstart = b >> 24;
-          blen = (uint32_t)(b & 0xFFFFFFu);
-        }
-        // ---- compact non-empty probes into the LDS list, chunk counts -> prefix
-        bool act = blen > 0;
-        uint64_t am = __ballot(act);
-        nact = __popcll(am);
-        uint32_t myix = __popcll(am & ((1ull << lane) - 1ull));
-        uint32_t nchunks = act ? (uint32_t)(((bstart & 3u) + blen + 3u) >> 2) : 0u;
-        uint32_t inc = nchunks; // inclusive scan over lanes (inactive lanes add 0)
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          uint32_t t = __shfl_up(inc, d);
-          if (lane >= (uint32_t)d) inc += t;
-        }
-        total = __shfl(inc, 63);
-        if (act) {
-          pl.start[myix] = bstart;
-          pl.len[myix] = blen;
-          pl.q[myix] = fe.enc32[strand];
-          pl.tag[myix] = make_tag(64u * pp + lane, (uint32_t)strand, 0, (uint32_t)lib);
-          pl.pre[myix] = inc - nchunks;
-        }
-        if (lane == 0) pl.pre[nact] = total;
+    uint32_t nv = 0;
+    Cand cur = fetch_group(ix, sb, 0, npos_seg, nv);
+    onmers += nv;
+    const int ngroups = npos_seg > 64 ? 2 : 1;
+    for (int pp = 0; pp < ngroups; ++pp) {
+      // descriptors of the NEXT group are requested before this group is scanned
+      Cand nxt = cur;
+      if (pp + 1 < ngroups) {
+        nxt = fetch_group(ix, sb, pp + 1, npos_seg, nv);
+        onmers += nv;
       }
-      __syncthreads();
-      // ---- scan: lanes flattened over 16-byte chunks of all listed buckets
-      for (uint32_t c0 = 0;; c0 += 64) {
-        if (rnd == 4 || ws.top > (uint32_t)(kStackCap - 256 - 64)) expand_all(ix, tb, ws);
-        if (c0 >= total) break;
-        uint32_t c = c0 + lane;
-        bool on = c < total;
-        uint32_t pi = 0;
-        if (on) { // largest pi with pre[pi] <= c
-          uint32_t lo = 0, hi = nact;
-          while (hi - lo > 1) {
-            uint32_t mid = (lo + hi) >> 1;
-            if (pl.pre[mid] <= c)
-              lo = mid;
-            else
-              hi = mid;
-          }
-          pi = lo;
+      // ---- compact the non-empty probes of this group into the LDS list
+      uint32_t len0 = (uint32_t)(cur.b[0] & 0xFFFFFFu), len1 = (uint32_t)(cur.b[1] & 0xFFFFFFu);
+      bool a0 = len0 > 0, a1 = len1 > 0;
+      uint64_t m0 = __ballot(a0), m1 = __ballot(a1);
+      uint32_t n0 = __popcll(m0), nact = n0 + __popcll(m1);
+      uint32_t ch0 = a0 ? (uint32_t)((((cur.b[0] >> 24) & 3u) + len0 + 3u) >> 2) : 0u;
+      uint32_t ch1 = a1 ? (uint32_t)((((cur.b[1] >> 24) & 3u) + len1 + 3u) >> 2) : 0u;
+      // inclusive scans in list order: all strand-0 probes, then all strand-1 probes
+      uint32_t s0 = ch0, s1 = ch1;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t0 = __shfl_up(s0, d), t1 = __shfl_up(s1, d);
+        if (lane >= (uint32_t)d) {
+          s0 += t0;
+          s1 += t1;
         }
-        uint32_t hitmask = 0, hds = 0;
-        uint64_t e0 = 0;
-        uint32_t ptag = 0;
-        if (on) {
-          uint64_t st = pl.start[pi];
-          uint32_t ln = pl.len[pi];
-          uint32_t q = pl.q[pi];
-          ptag = pl.tag[pi];
-          uint32_t ci = c - pl.pre[pi];
-          e0 = (st & ~3ull) + 4ull * ci;
-          const DevLib& L = ix.libs[(ptag >> 13) & 15u];
-          uint4 v = *reinterpret_cast<const uint4*>(L.enc + e0);
-          uint32_t ev[4] = {v.x, v.y, v.z, v.w};
+      }
+      uint32_t tot0 = __shfl(s0, 63), total = tot0 + __shfl(s1, 63);
+      if (a0) {
+        uint32_t i = __popcll(m0 & lt);
+        pl.bkt[i] = cur.b[0];
+        pl.q[i] = cur.q[0];
+        pl.tag[i] = (64u * pp + lane) | (cur.lib[0] << 8);
+        pl.pre[i] = s0 - ch0;
+      }
+      if (a1) {
+        uint32_t i = n0 + __popcll(m1 & lt);
+        pl.bkt[i] = cur.b[1];
+        pl.q[i] = cur.q[1];
+        pl.tag[i] = (64u * pp + lane) | (1u << 7) | (cur.lib[1] << 8);
+        pl.pre[i] = tot0 + s1 - ch1;
+      }
+      if (lane == 0) pl.pre[nact] = total;
+      __syncthreads();
+      // ---- scan: lanes flattened over 16-byte chunks of all listed buckets, two chunks per lane
+      for (uint32_t c0 = 0; c0 < total; c0 += 128) {
+        ChunkHits H[2];
+        uint4 v[2];
+        uint64_t st[2];
+        uint32_t ln[2], qq[2];
+        bool on[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          uint32_t c = c0 + 64u * u + lane;
+          on[u] = c < total;
+          H[u].mask = 0, H[u].hds = 0, H[u].e0 = 0, H[u].tag = 0;
+          st[u] = 0, ln[u] = 0, qq[u] = 0;
+          v[u] = make_uint4(0, 0, 0, 0);
+          if (on[u]) {
+            uint32_t pi = find_probe(pl, nact, c);
+            uint64_t b = pl.bkt[pi];
+            st[u] = b >> 24;
+            ln[u] = (uint32_t)(b & 0xFFFFFFu);
+            qq[u] = pl.q[pi];
+            H[u].tag = pl.tag[pi];
+            H[u].e0 = (st[u] & ~3ull) + 4ull * (c - pl.pre[pi]);
+            DevLib L = get_lib(ix, tag_lib(H[u].tag));
+            v[u] = *reinterpret_cast<const uint4*>(L.enc + H[u].e0);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (!on[u]) continue;
+          uint32_t e4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            uint64_t idx = e0 + e;
-            uint32_t hd = hd_lr32(ev[e], q);
-            bool hit = idx >= st && idx < st + ln && hd <= P.th;
-            hitmask |= hit ? (1u << e) : 0u;
-            hds |= hit ? (hd << (8 * e)) : 0u;
+            uint64_t idx = H[u].e0 + e;
+            uint32_t hd = hd_lr32(e4[e], qq[u]);
+            bool hit = idx >= st[u] && idx < st[u] + ln[u] && hd <= P.th;
+            H[u].mask |= hit ? (1u << e) : 0u;
+            H[u].hds |= hit ? (hd << (8 * e)) : 0u;
           }
         }
-        // ---- hits -> work stack (four ballot rounds, one per entry slot)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          bool hit = (hitmask >> e) & 1u;
-          uint64_t hm = __ballot(hit);
-          if (hm == 0) continue;
-          if (hit) {
+        // ---- hits -> work stack as unresolved items (their colour is fetched by expand_all)
+        uint32_t pend = H[0].mask | (H[1].mask << 4);
+        while (__ballot(pend != 0) != 0) {
+          if (ws.top > (uint32_t)(kStackCap - 64)) expand_all<GT, TAP>(ix, out, tb, ws);
+          bool has = pend != 0;
+          uint32_t bit = has ? (uint32_t)__ffs((int)pend) - 1u : 0u;
+          uint32_t u = bit >> 2, e = bit & 3u;
+          uint64_t hm = __ballot(has);
+          if (has) {
+            uint32_t hds = u ? H[1].hds : H[0].hds;
+            uint32_t tg = u ? H[1].tag : H[0].tag;
+            uint64_t idx = (u ? H[1].e0 : H[0].e0) + e;
             uint32_t hd = (hds >> (8 * e)) & 31u;
-            uint32_t st = (ptag >> 7) & 1u;
-            filt[st] = min(filt[st], hd);
-            uint32_t libi = (ptag >> 13) & 15u;
-            uint32_t se = ix.libs[libi].se[e0 + e];
-            uint32_t off = __popcll(hm & ((1ull << lane) - 1ull));
-            ws.stack[ws.top + off] = make_uint2(se, ptag | (hd << 8));
-            if (TAP) {
-              uint32_t hix = atomicAdd(&out.counters[3], 1u);
-              if (hix < out.hit_cap) {
-                kr_hit h;
-                h.read = read;
-                h.kpos = (uint32_t)base0 + (ptag & 127u);
-                h.strand = st;
-                h.lib = libi;
-                h.cmer_index = e0 + e;
-                h.hd = hd;
-                h.se = se;
-                out.hits[hix] = h;
-              } else {
-                atomicOr(&out.counters[1], kErrHitCap);
-              }
-            }
+            if (tag_strand(tg))
+              filt1 = min(filt1, hd);
+            else
+              filt0 = min(filt0, hd);
+            uint32_t hi = tg | (hd << 12) | ((uint32_t)(idx >> 32) << 17) | kItemUnresolved;
+            ws.stack[ws.top + __popcll(hm & lt)] = make_uint2((uint32_t)idx, hi);
+            pend &= pend - 1u;
           }
           ws.top += __popcll(hm);
+          __syncthreads();
         }
-        __syncthreads();
       }
       __syncthreads();
+      cur = nxt;
     }
+    expand_all<GT, TAP>(ix, out, tb, ws);
     // ---- fold this segment's planes into running counts (positions of different
     //      segments are distinct, so histograms add)
-    if (GT) {
-      __syncthreads();
-      uint32_t nt = *tb.ntouched;
-      for (uint32_t t = lane; t < nt; t += 64) {
-        uint32_t s = tb.touched[t];
-        uint32_t cum[kPlaneWords] = {0, 0, 0, 0};
-        for (uint32_t x = 0; x < tb.np; ++x) {
-          uint32_t add = 0;
-          for (int w = 0; w < kPlaneWords; ++w) {
-            uint32_t i = (s * tb.np + x) * kPlaneWords + w;
-            uint32_t pw = tb.load_plane(i);
-            add += __popc(pw & ~cum[w]);
-            cum[w] |= pw;
-            tb.store_plane(i, 0);
-          }
-          uint32_t ci = s * tb.np + x;
-          tb.store_count(ci, tb.load_count(ci) + add);
-        }
-      }
-    } else {
-      for (uint32_t s = lane; s <= tb.mask; s += 64) {
-        if (tb.keys[s] == 0) continue;
-        uint32_t cum[kPlaneWords] = {0, 0, 0, 0};
-        for (uint32_t x = 0; x < tb.np; ++x) {
-          uint32_t add = 0;
-          for (int w = 0; w < kPlaneWords; ++w) {
-            uint32_t i = (s * tb.np + x) * kPlaneWords + w;
-            uint32_t pw = tb.planes[i];
-            add += __popc(pw & ~cum[w]);
-            cum[w] |= pw;
-            tb.planes[i] = 0;
-          }
-          tb.counts[s * tb.np + x] += add;
-        }
+    __syncthreads();
+    uint32_t nfold = GT ? *tb.ntouched : (tb.mask + 1);
+    for (uint32_t t = lane; t < nfold; t += 64) {
+      uint32_t s = GT ? tb.touched[t] : t;
+      if (!GT && tb.keys[s] == 0) continue;
+      uint32_t cum0 = 0, cum1 = 0, cum2 = 0, cum3 = 0;
+      for (uint32_t x = 0; x < tb.np; ++x) {
+        uint32_t i = (s * tb.np + x) * kPlaneWords;
+        uint32_t w0 = tb.load_plane(i), w1 = tb.load_plane(i + 1), w2 = tb.load_plane(i + 2), w3 = tb.load_plane(i + 3);
+        uint32_t add = __popc(w0 & ~cum0) + __popc(w1 & ~cum1) + __popc(w2 & ~cum2) + __popc(w3 & ~cum3);
+        cum0 |= w0, cum1 |= w1, cum2 |= w2, cum3 |= w3;
+        if (w0) tb.store_plane(i, 0);
+        if (w1) tb.store_plane(i + 1, 0);
+        if (w2) tb.store_plane(i + 2, 0);
+        if (w3) tb.store_plane(i + 3, 0);
+        if (add) tb.store_count(s * tb.np + x, tb.load_count(s * tb.np + x) + add);
       }
     }
     __syncthreads();
@@ -632,8 +703,8 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   // ---- per-strand hdist_filt = min hd over kept table entries (src/query.cpp:366-368)
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
-    filt[0] = min(filt[0], (uint32_t)__shfl_xor(filt[0], d));
-    filt[1] = min(filt[1], (uint32_t)__shfl_xor(filt[1], d));
+    filt0 = min(filt0, (uint32_t)__shfl_xor(filt0, d));
+    filt1 = min(filt1, (uint32_t)__shfl_xor(filt1, d));
   }
   bool ovf = __ballot(ws.overflow) != 0;
   if (ws.err && lane == 0) atomicOr(&out.counters[1], ws.err);
@@ -646,31 +717,23 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
       out.rd_cnt[read] = 0;
       out.rd_off[read] = 0;
     }
+    clear_lds_table(tb);
     return;
   }
   if (ovf && GT && lane == 0) atomicOr(&out.counters[1], kErrTable);
 
   // ---- emit records that pass `hdist_min <= 2*hdist_filt+1` (src/query.cpp:101-106,119),
   //      ordered by key so that the two strands of a leaf are adjacent.
-  const uint32_t lim[2] = {2u * filt[0] + 1u, 2u * filt[1] + 1u}; // u32 wrap keeps "none" = max
+  const uint32_t lim0 = 2u * filt0 + 1u, lim1 = 2u * filt1 + 1u; // u32 wrap keeps "none" = max
   uint32_t nslots = GT ? *tb.ntouched : (tb.mask + 1);
   uint32_t nrec = 0;
-  // pass 1: count
   for (uint32_t t0 = 0; t0 < nslots; t0 += 64) {
     uint32_t t = t0 + lane;
     bool ok = false;
     if (t < nslots) {
       uint32_t s = GT ? tb.touched[t] : t;
       uint32_t key = tb.load_key(s);
-      if (key) {
-        uint32_t hmin = 0xFFFFFFFFu;
-        for (uint32_t x = 0; x < tb.np; ++x)
-          if (tb.load_count(s * tb.np + x)) {
-            hmin = x;
-            break;
-          }
-        ok = hmin <= lim[key & 1u];
-      }
+      if (key) ok = tb.hdist_min(s) <= ((key & 1u) ? lim1 : lim0);
     }
     nrec += __popcll(__ballot(ok));
   }
@@ -684,44 +747,54 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
     out.rd_off[read] = rbase == 0xFFFFFFFFu ? 0 : rbase;
     out.rd_cnt[read] = rbase == 0xFFFFFFFFu ? 0 : nrec;
     out.rd_onmers[read] = onmers;
-    out.rd_filt[2 * read] = filt[0];
-    out.rd_filt[2 * read + 1] = filt[1];
+    out.rd_filt[2 * read] = filt0;
+    out.rd_filt[2 * read + 1] = filt1;
   }
   rbase = __shfl(rbase, 0);
-  // pass 2: rank by key and write
-  if (rbase != 0xFFFFFFFFu && nrec) {
-    for (uint32_t t0 = 0; t0 < nslots; t0 += 64) {
-      uint32_t t = t0 + lane;
-      if (t >= nslots) continue;
-      uint32_t s = GT ? tb.touched[t] : t;
-      uint32_t key = tb.load_key(s);
-      if (!key) continue;
-      uint32_t hmin = 0xFFFFFFFFu;
-      for (uint32_t x = 0; x < tb.np; ++x)
-        if (tb.load_count(s * tb.np + x)) {
-          hmin = x;
-          break;
+  // rank of a record = number of passing keys smaller than its own: for every tile of 64 slots,
+  // walk the passing lanes of every tile with a wave-uniform readlane (a handful of steps)
+  for (uint32_t tA = 0; tA < nslots; tA += 64) {
+    uint32_t t = tA + lane;
+    uint32_t sA = 0, keyA = 0;
+    bool okA = false;
+    if (t < nslots) {
+      sA = GT ? tb.touched[t] : t;
+      keyA = tb.load_key(sA);
+      if (keyA) okA = tb.hdist_min(sA) <= ((keyA & 1u) ? lim1 : lim0);
+    }
+    uint32_t rank = 0;
+    for (uint32_t tB = 0; tB < nslots; tB += 64) {
+      uint32_t keyB = keyA;
+      bool okB = okA;
+      if (tB != tA) {
+        uint32_t u = tB + lane;
+        keyB = 0, okB = false;
+        if (u < nslots) {
+          uint32_t sB = GT ? tb.touched[u] : u;
+          keyB = tb.load_key(sB);
+          if (keyB) okB = tb.hdist_min(sB) <= ((keyB & 1u) ? lim1 : lim0);
         }
-      if (hmin > lim[key & 1u]) continue;
-      uint32_t rank = 0;
-      for (uint32_t u = 0; u < nslots; ++u) {
-        uint32_t s2 = GT ? tb.touched[u] : u;
-        uint32_t k2 = tb.load_key(s2);
-        if (k2 == 0 || k2 >= key) continue;
-        uint32_t h2 = 0xFFFFFFFFu;
-        for (uint32_t x = 0; x < tb.np; ++x)
-          if (tb.load_count(s2 * tb.np + x)) {
-            h2 = x;
-            break;
-          }
-        rank += h2 <= lim[k2 & 1u];
       }
+      uint64_t mB = __ballot(okB);
+      while (mB) {
+        int u = __ffsll((long long)mB) - 1;
+        uint32_t kb = __shfl(keyB, u);
+        rank += (kb < keyA) ? 1u : 0u;
+        mB &= mB - 1;
+      }
+    }
+    if (okA && rbase != 0xFFFFFFFFu) {
       uint32_t ri = rbase + rank;
       out.rec_read[ri] = read;
-      out.rec_key[ri] = key;
-      for (uint32_t x = 0; x < tb.np; ++x) out.rec_hist[(uint64_t)ri * tb.np + x] = tb.load_count(s * tb.np + x);
+      out.rec_key[ri] = keyA;
+      for (uint32_t x = 0; x < tb.np; ++x) out.rec_hist[(uint64_t)ri * tb.np + x] = tb.load_count(sA * tb.np + x);
+    }
+    if (!GT && keyA) { // LDS table: the owning lane leaves its slot empty for the next read
+      tb.keys[sA] = 0;
+      for (uint32_t x = 0; x < tb.np; ++x) tb.counts[sA * tb.np + x] = 0;
     }
   }
+  if (!GT) __syncthreads();
   // ---- global table: clear what this read touched
   if (GT) {
     __syncthreads();
@@ -744,14 +817,12 @@ __global__ __launch_bounds__(kWave) void kr_probe_kernel_t(DevIndex ix, DevParam
   //   stack | probe list | ntouched | [LDS table: keys, planes, counts]
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   uint2* s_stack = reinterpret_cast<uint2*>(s_dyn);
-  uint64_t* s_start = reinterpret_cast<uint64_t*>(s_stack + kStackCap);
-  uint32_t* s_len = reinterpret_cast<uint32_t*>(s_start + 64);
-  uint32_t* s_q = s_len + 64;
-  uint32_t* s_tag = s_q + 64;
-  uint32_t* s_pre = s_tag + 64; // 65 used, 68 reserved
-  uint32_t* s_ntouched_p = s_pre + 68;
+  uint64_t* s_bkt = reinterpret_cast<uint64_t*>(s_stack + kStackCap);
+  uint32_t* s_q = reinterpret_cast<uint32_t*>(s_bkt + kListCap);
+  uint32_t* s_tag = s_q + kListCap;
+  uint32_t* s_pre = s_tag + kListCap; // 129 used, 132 reserved
+  uint32_t* s_ntouched_p = s_pre + kListCap + 4;
   uint32_t* s_tbl = s_ntouched_p + 4;
-#define s_ntouched (*s_ntouched_p)
 
   Table<GT> tb;
   tb.np = P.np;
@@ -770,15 +841,17 @@ __global__ __launch_bounds__(kWave) void kr_probe_kernel_t(DevIndex ix, DevParam
     tb.touched = nullptr;
     tb.mask = kLdsSlots - 1;
   }
-  if (threadIdx.x == 0) s_ntouched = 0;
+  if (threadIdx.x == 0) *s_ntouched_p = 0;
   __syncthreads();
+  clear_lds_table(tb);
   WaveState ws;
   ws.stack = s_stack;
   ws.top = 0;
   ws.overflow = false;
   ws.err = 0;
-  ProbeList pl{s_start, s_len, s_q, s_tag, s_pre};
-#undef s_ntouched
+  ws.read = 0;
+  ws.base0 = 0;
+  ProbeList pl{s_bkt, s_q, s_tag, s_pre};
 
   if (GT) {
     uint32_t n = out.counters[2];
@@ -1053,7 +1126,7 @@ __global__ void kr_relayout_inc(const uint64_t* inc, uint32_t nrows, uint64_t* b
 // dynamic LDS bytes of the probe kernel: stack + probe list + ntouched (+ table)
 uint32_t probe_lds_bytes(bool global_table, uint32_t np)
 {
-  uint32_t b = kStackCap * 8 + 64 * 8 + 3 * 64 * 4 + 68 * 4 + 16;
+  uint32_t b = kStackCap * 8 + kListCap * 8 + 2 * kListCap * 4 + (kListCap + 4) * 4 + 16;
   if (!global_table) b += kLdsSlots * 4 + kLdsSlots * np * kPlaneWords * 4 + kLdsSlots * np * 4;
   return (b + 15u) & ~15u;
 }
@@ -1109,6 +1182,7 @@ namespace {
 
 struct DescHeader {
   uint32_t magic, k, h, m, nlibs, tree_nnodes;
+  uint64_t res_mask;
   uint8_t ppos[32], npos[32];
 };
 struct DescLib {
@@ -1172,6 +1246,8 @@ int alloc_from_desc(kr_index* ix, const DescHeader& H, const std::vector<DescLib
   if ((rc = dev_alloc(ix, &p, b))) return rc;
   ix->dix.libs = (const DevLib*)p;
   HIP_TRY(hipMemcpy(p, ix->hlibs.data(), b, hipMemcpyHostToDevice)); // pointers are per-device: never exported
+  ix->dix.lib0 = ix->hlibs[0];
+  ix->dix.res_mask = H.res_mask;
 
   ix->dix.k = H.k, ix->dix.h = H.h, ix->dix.m = H.m, ix->dix.nlibs = H.nlibs, ix->dix.tree_nnodes = H.tree_nnodes;
   ix->dix.m_shift = 0xFFFFFFFFu;
@@ -1230,6 +1306,8 @@ int kr_index_upload(const kr_index_view* v, int device, uint32_t flags, kr_index
     else
       res_lib[lv.r] = (int32_t)i;
   }
+  for (uint32_t q = 0; q < v->m && q < 64; ++q)
+    if (res_lib[q] >= 0) H.res_mask |= 1ull << q;
   std::unique_ptr<kr_index> ix(new kr_index());
   ix->device = device;
   int rc = alloc_from_desc(ix.get(), H, L);
@@ -1431,7 +1509,9 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   s->max_reads = max_reads, s->max_bases = max_bases;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
-  s->nwaves = (uint32_t)prop.multiProcessorCount * 12u;
+  // resident waves per CU: LDS-limited (160 KiB per CU), VGPR-limited to 5 waves per SIMD
+  uint32_t per_cu = std::min<uint32_t>(20u, 163840u / probe_lds_bytes(false, p->hdist_th + 1));
+  s->nwaves = (uint32_t)prop.multiProcessorCount * std::max<uint32_t>(1u, per_cu);
   s->ovf_waves = (uint32_t)prop.multiProcessorCount * 2u;
   uint32_t nleaves2 = 2u * (ix->dix.tree_nnodes + 1);
   uint32_t g_slots = std::min<uint32_t>(next_pow2(std::max<uint32_t>(256u, 2u * nleaves2)), 1u << 16);

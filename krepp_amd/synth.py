@@ -184,3 +184,23 @@ def write_fastq(path, bases, offsets, names):
         for i, nm in enumerate(names):
             s = bases[int(offsets[i]):int(offsets[i + 1])].tobytes()
             f.write(b"@" + nm.encode() + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n")
+
+
+def yule_newick(n, seed, mean_blen=0.02, prefix="g"):
+    """Random rooted binary tree with n leaves (uniform random joins), branch lengths Exp(mean)."""
+    rng = Rng(seed, 3)
+    width = len(str(n - 1))
+    items = [f"{prefix}{i:0{width}d}" for i in range(n)]
+    bl = -np.log(1.0 - rng.uniform(2 * n)) * mean_blen
+    picks = rng.u64(2 * n)
+    bi = 0
+    pi = 0
+    while len(items) > 1:
+        i = int(picks[pi] % np.uint64(len(items)))
+        a = items.pop(i)
+        j = int(picks[pi + 1] % np.uint64(len(items)))
+        b = items.pop(j)
+        pi += 2
+        items.append(f"({a}:{bl[bi]:.6f},{b}:{bl[bi + 1]:.6f})")
+        bi += 2
+    return items[0] + ";"

@@ -1116,6 +1116,20 @@ ko_index* ko_index_load(const char* dir, char* err, int errlen)
 
 void ko_index_free(ko_index* ix) { delete ix; }
 
+// Replace the bucket table of one library with caller-supplied arrays in the on-disk layout
+// (inc: cumulative ends; cmer: interleaved enc32,se).  Used by bench.py for the synthetic
+// HBM-resident index, whose table is generated on the GPU and never written to disk.
+int ko_index_replace_table(ko_index* ix, uint32_t lib, const uint64_t* inc, uint32_t nrows, const uint32_t* cmer,
+                           uint64_t nkmers)
+{
+  if (!ix || lib >= ix->libs.size() || !inc || !cmer) return -1;
+  Lib& L = ix->libs[lib];
+  L.inc.assign(inc, inc + nrows);
+  L.cmer.resize(nkmers);
+  memcpy(L.cmer.data(), cmer, nkmers * 8);
+  return 0;
+}
+
 void ko_index_info(const ko_index* ix, ko_info* o)
 {
   memset(o, 0, sizeof(*o));

@@ -120,6 +120,8 @@ typedef struct ko_result {
 
 ko_index* ko_index_load(const char* dir, char* err, int errlen);
 void ko_index_free(ko_index*);
+int ko_index_replace_table(ko_index*, uint32_t lib, const uint64_t* inc, uint32_t nrows, const uint32_t* cmer,
+                           uint64_t nkmers);
 void ko_index_info(const ko_index*, ko_info* out);
 /* name as printed by the reference (Node::get_name, src/phytree.hpp:134-145) */
 const char* ko_node_name(const ko_index*, uint32_t se);

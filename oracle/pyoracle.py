@@ -63,6 +63,7 @@ def lib():
         l.ko_index_load.restype = vp
         l.ko_index_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         l.ko_index_free.argtypes = [vp]
+        l.ko_index_replace_table.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64]
         l.ko_index_info.argtypes = [vp, C.POINTER(KoInfo)]
         l.ko_node_name.argtypes = [vp, C.c_uint32]
         l.ko_node_name.restype = C.c_char_p
@@ -124,6 +125,13 @@ class Index:
         if not self.h:
             raise RuntimeError("oracle: " + err.value.decode())
         self.info = KoInfo()
+        self.l.ko_index_info(self.h, C.byref(self.info))
+
+    def replace_table(self, lib_ix, inc, cmer):
+        inc = np.ascontiguousarray(inc, dtype=np.uint64)
+        cmer = np.ascontiguousarray(cmer, dtype=np.uint32)
+        rc = self.l.ko_index_replace_table(self.h, lib_ix, inc.ctypes.data, len(inc), cmer.ctypes.data, cmer.size // 2)
+        assert rc == 0
         self.l.ko_index_info(self.h, C.byref(self.info))
 
     def name(self, se):
