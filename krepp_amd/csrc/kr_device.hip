@@ -55,7 +55,8 @@ constexpr int kPlaneWords = kSegPos / 32;
 constexpr int kMaxRuns = 16;
 constexpr int kMaxLibs = 16;
 constexpr int kStackCap = 256;    // colour work stack (items of 8 B)
-constexpr int kLdsSlots = 64;     // LDS accumulator table entries per wave
+constexpr int kLdsSlots = 64;     // level-1 (LDS) accumulator slots per wave: lane t owns slot t in the epilogue
+constexpr int kLdsProbeMax = 8;   // bounded probe sequence of the level-1 table
 constexpr int kMaxPlanes = KR_MAX_HDIST_TH + 1;
 
 struct Runs {
@@ -77,7 +78,9 @@ struct DevIndex {
   uint32_t k, h, m, nlibs, tree_nnodes;
   uint32_t m_shift;      // log2(m) if m is a power of two, else 0xFFFFFFFF
   Runs prun, nrun;       // contiguous runs of the LSH / non-LSH position lists
-  const uint8_t* kind;   // [tree_nnodes+1] 0 null, 1 leaf, 2 internal
+  uint32_t nleaves;
+  const uint32_t* node_info; // [tree_nnodes+1] kind (0 null, 1 leaf, 2 internal) | leaf_rank << 2
+  const uint32_t* leaf_se;   // [nleaves] colour id of the leaf with a given rank (ranks follow se order)
   const int32_t* res_lib; // [m] library serving each residue, or -1
   const DevLib* libs;    // [nlibs] in device memory
   uint64_t res_mask;     // nlibs == 1 && m <= 64: bit r set iff residue r is served
@@ -98,7 +101,7 @@ struct DevParams {
 
 // Everything the kernels write for one batch.
 struct BatchOut {
-  uint32_t* counters;    // [0] nrec  [1] error flags  [2] n overflow reads  [3] nhits(tap)
+  uint32_t* counters;    // [0] nrec  [1] error flags  [2] reads that used level 2  [3] nhits(tap)
   uint32_t* rd_off;
   uint32_t* rd_cnt;
   uint32_t* rd_onmers;
@@ -112,15 +115,14 @@ struct BatchOut {
   double* rec_chisq;
   uint8_t* rec_sel;
   uint32_t rec_cap;
-  uint32_t* ovf_list;    // reads to redo with the global table
   kr_hit* hits;
   uint32_t hit_cap;
-  // global accumulator scratch for the overflow kernel
-  uint32_t* g_keys;      // [nwaves * g_slots]
-  uint32_t* g_planes;    // [nwaves * g_slots * np * 4]
-  uint32_t* g_counts;    // [nwaves * g_slots * np]
-  uint32_t* g_touched;   // [nwaves * g_slots]
-  uint32_t g_slots;      // power of two
+  // level-2 accumulator scratch, one region per resident wave
+  uint32_t* g_planes; // [nwaves][nslots2][np][4]
+  uint32_t* g_counts; // [nwaves][nslots2][np]
+  uint32_t* g_list;   // [nwaves][nslots2]
+  uint32_t nslots2;   // 2 * nleaves
+  uint32_t bm_words;  // ceil(nslots2 / 32)
 };
 
 enum : uint32_t { kErrRecCap = 1u, kErrStack = 2u, kErrTable = 4u, kErrHitCap = 8u };
@@ -255,104 +257,27 @@ __device__ __forceinline__ bool locate_row(const DevIndex& ix, uint32_t rix, int
 }
 
 // ---------------------------------------------------------------------------
-// Accumulator table.  GT = false: LDS (ds_ atomics); GT = true: global scratch with
-// agent-scope atomics (L2), reads bypass the per-CU L1.
+// Accumulators.  Level 1: 64-slot open-addressing hash table in LDS, keyed
+// (se << 1) | strand, probe sequences bounded to 8 slots.  Level 2 (only for reads whose
+// keys do not fit level 1): direct-indexed by slot2 = 2 * leaf_rank + strand in a per-wave
+// global scratch region, with an LDS bitmap of the touched slots.  A key lives in exactly one
+// level: slots never empty during a read, so a bounded probe that failed once fails again.
 // ---------------------------------------------------------------------------
-template <bool GT>
-struct Table {
-  uint32_t* keys;
-  uint32_t* planes;
-  uint32_t* counts;
-  uint32_t* touched;  // GT only
-  uint32_t* ntouched; // GT only (LDS word)
-  uint32_t mask;      // slots - 1
-  uint32_t np;
-
-  __device__ __forceinline__ uint32_t load_key(uint32_t s) const
-  {
-    if (GT) return __hip_atomic_load(&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return ((volatile uint32_t*)keys)[s];
-  }
-  __device__ __forceinline__ uint32_t cas_key(uint32_t s, uint32_t key) const
-  {
-    if (GT) {
-      uint32_t expected = 0;
-      __hip_atomic_compare_exchange_strong(&keys[s], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-      return expected;
-    }
-    return atomicCAS(&keys[s], 0u, key);
-  }
-  // returns slot or -1 when the table is full
-  __device__ __forceinline__ int find_or_insert(uint32_t key) const
-  {
-    uint32_t s = (hash_key(key) >> 8) & mask;
-    for (uint32_t i = 0; i <= mask; ++i) {
-      uint32_t cur = load_key(s);
-      if (cur == key) return (int)s;
-      if (cur == 0) {
-        uint32_t old = cas_key(s, key);
-        if (old == 0) {
-          if (GT) {
-            uint32_t t = atomicAdd(ntouched, 1u);
-            touched[t] = s;
-          }
-          return (int)s;
-        }
-        if (old == key) return (int)s;
-      }
-      s = (s + 1) & mask;
-    }
-    return -1;
-  }
-  __device__ __forceinline__ void or_bit(int slot, uint32_t hd, uint32_t pos) const
-  {
-    uint32_t* w = &planes[((uint32_t)slot * np + hd) * kPlaneWords + (pos >> 5)];
-    uint32_t bit = 1u << (pos & 31);
-    if (GT)
-      __hip_atomic_fetch_or(w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-      atomicOr(w, bit);
-  }
-  __device__ __forceinline__ uint32_t load_plane(uint32_t i) const
-  {
-    if (GT) return __hip_atomic_load(&planes[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return planes[i];
-  }
-  __device__ __forceinline__ void store_plane(uint32_t i, uint32_t v) const
-  {
-    if (GT)
-      __hip_atomic_store(&planes[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-      planes[i] = v;
-  }
-  __device__ __forceinline__ uint32_t load_count(uint32_t i) const
-  {
-    if (GT) return __hip_atomic_load(&counts[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return counts[i];
-  }
-  __device__ __forceinline__ void store_count(uint32_t i, uint32_t v) const
-  {
-    if (GT)
-      __hip_atomic_store(&counts[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-      counts[i] = v;
-  }
-  __device__ __forceinline__ void store_key(uint32_t s, uint32_t v) const
-  {
-    if (GT)
-      __hip_atomic_store(&keys[s], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-      keys[s] = v;
-  }
-  // smallest x with a non-zero count, or 0xFFFFFFFF
-  __device__ __forceinline__ uint32_t hdist_min(uint32_t s) const
-  {
-    for (uint32_t x = 0; x < np; ++x)
-      if (load_count(s * np + x)) return x;
-    return 0xFFFFFFFFu;
-  }
+struct Acc {
+  // level 1 (LDS)
+  uint32_t* keys;    // [kLdsSlots]
+  uint32_t* planes;  // [kLdsSlots * np * 4]
+  uint32_t* counts;  // [kLdsSlots * np]
+  // level 2
+  uint32_t* bitmap;   // LDS [bm_words]
+  uint32_t* g_planes; // global [nslots2 * np * 4]
+  uint32_t* g_counts; // global [nslots2 * np]
+  uint32_t* g_list;   // global [nslots2]
+  uint32_t nslots2, bm_words, np;
 };
+
+__device__ __forceinline__ uint32_t gload(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gstore(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Work-stack item (8 B).  hi = pos(7) | strand(1)<<7 | lib(4)<<8 | hd(5)<<12 | idx_hi(8)<<17 |
 // unresolved<<31.  Resolved: lo = colour id.  Unresolved (a fresh table hit whose colour has not
@@ -364,12 +289,12 @@ __device__ __forceinline__ uint32_t tag_lib(uint32_t t) { return (t >> 8) & 15u;
 __device__ __forceinline__ uint32_t tag_hd(uint32_t t) { return (t >> 12) & 31u; }
 
 struct WaveState {
-  uint2* stack;  // LDS [kStackCap]
-  uint32_t top;  // wave-uniform
-  bool overflow; // table full for this read (any lane)
+  uint2* stack;   // LDS [kStackCap]
+  uint32_t top;   // wave-uniform
+  bool l2;        // this lane sent something to level 2 during this read
   uint32_t err;
-  uint32_t read;   // for the hit tap
-  uint32_t base0;  // first k-mer position of the current segment
+  uint32_t read;  // for the hit tap
+  uint32_t base0; // first k-mer position of the current segment
 };
 
 __device__ __forceinline__ DevLib get_lib(const DevIndex& ix, uint32_t lib)
@@ -378,52 +303,52 @@ __device__ __forceinline__ DevLib get_lib(const DevIndex& ix, uint32_t lib)
   return ix.libs[lib];
 }
 
-// zero the whole LDS table (kernel start, and after a read that overflowed it)
-__device__ __forceinline__ void clear_lds_table(const Table<false>& tb)
+// Minfo::update_match (src/query.hpp:153-176) as an idempotent OR: bit `pos` of plane `hd`.
+__device__ __forceinline__ void accumulate(const Acc& A, WaveState& ws, uint32_t se, uint32_t info, uint32_t tag)
 {
-  for (uint32_t s = lane_id(); s <= tb.mask; s += 64) {
-    tb.keys[s] = 0;
-    for (uint32_t x = 0; x < tb.np; ++x) {
-      tb.counts[s * tb.np + x] = 0;
-#pragma unroll
-      for (int w = 0; w < kPlaneWords; ++w) tb.planes[(s * tb.np + x) * kPlaneWords + w] = 0;
+  const uint32_t key = (se << 1) | tag_strand(tag);
+  const uint32_t hd = tag_hd(tag), pos = tag_pos(tag);
+  uint32_t s = (hash_key(key) >> 8) & (kLdsSlots - 1);
+#pragma unroll 1
+  for (int i = 0; i < kLdsProbeMax; ++i) {
+    uint32_t cur = ((volatile uint32_t*)A.keys)[s];
+    if (cur == 0) {
+      uint32_t old = atomicCAS(&A.keys[s], 0u, key);
+      cur = old == 0 ? key : old;
     }
+    if (cur == key) {
+      atomicOr(&A.planes[(s * A.np + hd) * kPlaneWords + (pos >> 5)], 1u << (pos & 31));
+      return;
+    }
+    s = (s + 1) & (kLdsSlots - 1);
   }
-  __syncthreads();
-}
-__device__ __forceinline__ void clear_lds_table(const Table<true>&) {}
-
-template <bool GT>
-__device__ __forceinline__ void accumulate(const Table<GT>& tb, WaveState& ws, uint32_t se, uint32_t tag)
-{
-  uint32_t key = (se << 1) | tag_strand(tag);
-  int slot = tb.find_or_insert(key);
-  if (slot < 0) {
-    ws.overflow = true;
-    return;
-  }
-  tb.or_bit(slot, tag_hd(tag), tag_pos(tag));
+  // level 2
+  const uint32_t slot2 = ((info >> 2) << 1) | tag_strand(tag);
+  atomicOr(&A.bitmap[slot2 >> 5], 1u << (slot2 & 31));
+  __hip_atomic_fetch_or(&A.g_planes[((uint64_t)slot2 * A.np + hd) * kPlaneWords + (pos >> 5)], 1u << (pos & 31),
+                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ws.l2 = true;
 }
 
 // classify one colour: leaf -> accumulate, null -> drop, anything else -> caller pushes it
-template <bool GT>
-__device__ __forceinline__ bool colour_needs_expansion(const DevIndex& ix, const Table<GT>& tb, WaveState& ws,
-                                                       uint32_t se, uint32_t tag)
+__device__ __forceinline__ bool colour_needs_expansion(const DevIndex& ix, const Acc& A, WaveState& ws, uint32_t se,
+                                                       uint32_t tag)
 {
   if (se == 0) return false;
   if (se <= ix.tree_nnodes) { // Tree::check_node (src/phytree.hpp:34)
-    uint32_t kd = ix.kind[se];
-    if (kd == 1) accumulate(tb, ws, se, tag);
-    return kd == 2;
+    uint32_t info = ix.node_info[se];
+    if ((info & 3u) == 1u) accumulate(A, ws, se, info, tag);
+    return (info & 3u) == 2u;
   }
   return true;
 }
 
 // Colour expansion (the BFS of src/query.cpp:369-387, order-free here): drain the work stack.
-template <bool GT, bool TAP>
-__device__ __forceinline__ void expand_all(const DevIndex& ix, const BatchOut& out, const Table<GT>& tb, WaveState& ws)
+template <bool TAP>
+__device__ __forceinline__ void expand_all(const DevIndex& ix, const BatchOut& out, const Acc& A, WaveState& ws)
 {
   const uint32_t lane = lane_id();
+  const uint64_t lt = (1ull << lane) - 1ull;
   while (ws.top > 0) {
     uint32_t room = kStackCap - ws.top;
     uint32_t n = min(min(64u, ws.top), room);
@@ -441,7 +366,6 @@ __device__ __forceinline__ void expand_all(const DevIndex& ix, const BatchOut& o
     bool p0 = false, p1 = false;
     if (have) {
       DevLib L = get_lib(ix, tag_lib(tag));
-      bool expand;
       if (tag & kItemUnresolved) { // fetch the colour of a fresh hit
         uint64_t idx = (uint64_t)item.x | ((uint64_t)((tag >> 17) & 0xFFu) << 32);
         se = L.se[idx];
@@ -463,17 +387,15 @@ __device__ __forceinline__ void expand_all(const DevIndex& ix, const BatchOut& o
         }
         tag &= 0x1FFFFu;
       }
-      expand = colour_needs_expansion(ix, tb, ws, se, tag);
-      if (expand) {
+      if (colour_needs_expansion(ix, A, ws, se, tag)) {
         uint2 pr = se < L.nsubsets ? L.pse[se] : make_uint2(0, 0);
         c0 = pr.x;
         c1 = pr.y;
-        p0 = colour_needs_expansion(ix, tb, ws, c0, tag);
-        p1 = colour_needs_expansion(ix, tb, ws, c1, tag);
+        p0 = colour_needs_expansion(ix, A, ws, c0, tag);
+        p1 = colour_needs_expansion(ix, A, ws, c1, tag);
       }
     }
     uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
-    uint64_t lt = (1ull << lane) - 1ull;
     if (p0) ws.stack[ws.top + __popcll(m0 & lt)] = make_uint2(c0, tag);
     ws.top += __popcll(m0);
     if (p1) ws.stack[ws.top + __popcll(m1 & lt)] = make_uint2(c1, tag);
@@ -483,20 +405,19 @@ __device__ __forceinline__ void expand_all(const DevIndex& ix, const BatchOut& o
 }
 
 // ---------------------------------------------------------------------------
-// The probe kernel body for one read.
+// Probe list of one group (64 positions x 2 strands) and the bucket scan.
 // ---------------------------------------------------------------------------
-constexpr int kListCap = 128; // probes per group: 64 positions x 2 strands
+constexpr int kListCap = 128;
 struct ProbeList {
-  uint64_t* bkt;  // [128] (start << 24) | len
-  uint32_t* q;    // [128] residual code of the query k-mer
-  uint32_t* tag;  // [128] pos | strand<<7 | lib<<8
-  uint32_t* pre;  // [129] exclusive prefix of 16-byte chunk counts
+  uint64_t* bkt; // [128] (start << 24) | len
+  uint32_t* q;   // [128] residual code of the query k-mer
+  uint32_t* tag; // [128] pos | strand<<7 | lib<<8
 };
 
 struct Cand { // one lane's two candidate probes (forward, reverse) of a position
-  uint64_t b[2];
-  uint32_t q[2];
-  uint32_t lib[2];
+  uint64_t b0, b1;
+  uint32_t q0, q1;
+  uint32_t lib0, lib1;
 };
 
 // front end + descriptor loads for positions 64*pp + lane
@@ -506,45 +427,172 @@ __device__ __forceinline__ Cand fetch_group(const DevIndex& ix, const SegBits& s
   Cand c;
   FrontEnd fe = front_end(ix, sb, pp, npos_seg);
   nvalid = __popcll(__ballot(fe.valid));
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    int lib = -1;
-    uint32_t row = 0;
-    c.b[s] = 0;
-    c.q[s] = fe.enc32[s];
-    c.lib[s] = 0;
-    if (fe.valid && locate_row(ix, fe.rix[s], lib, row)) {
-      c.lib[s] = (uint32_t)lib;
-      c.b[s] = get_lib(ix, (uint32_t)lib).bkt[row];
-    }
+  int lib = -1;
+  uint32_t row = 0;
+  c.b0 = 0, c.b1 = 0, c.lib0 = 0, c.lib1 = 0;
+  c.q0 = fe.enc32[0];
+  c.q1 = fe.enc32[1];
+  if (fe.valid && locate_row(ix, fe.rix[0], lib, row)) {
+    c.lib0 = (uint32_t)lib;
+    c.b0 = get_lib(ix, (uint32_t)lib).bkt[row];
+  }
+  if (fe.valid && locate_row(ix, fe.rix[1], lib, row)) {
+    c.lib1 = (uint32_t)lib;
+    c.b1 = get_lib(ix, (uint32_t)lib).bkt[row];
   }
   return c;
 }
 
-struct ChunkHits {
-  uint64_t e0;      // first entry index of the 16-byte chunk
-  uint32_t tag;     // probe tag
-  uint32_t mask;    // 4-bit hit mask
-  uint32_t hds;     // 4 x 8-bit hd
-};
-
-__device__ __forceinline__ uint32_t find_probe(const ProbeList& pl, uint32_t nact, uint32_t c)
-{ // largest pi with pre[pi] <= c
-  uint32_t lo = 0, hi = nact;
-  while (hi - lo > 1) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (pl.pre[mid] <= c)
-      lo = mid;
-    else
-      hi = mid;
-  }
-  return lo;
+// 4 entries of one 16-byte chunk against the query code: 4-bit hit mask, 4 x 8-bit hd
+__device__ __forceinline__ void chunk_hits(uint4 v, uint64_t e0, uint64_t st, uint32_t ln, uint32_t q, uint32_t th,
+                                           uint32_t& mask, uint32_t& hds)
+{
+  uint32_t h0 = hd_lr32(v.x, q), h1 = hd_lr32(v.y, q), h2 = hd_lr32(v.z, q), h3 = hd_lr32(v.w, q);
+  uint64_t en = st + ln;
+  bool b0 = e0 >= st && e0 < en && h0 <= th;
+  bool b1 = e0 + 1 >= st && e0 + 1 < en && h1 <= th;
+  bool b2 = e0 + 2 >= st && e0 + 2 < en && h2 <= th;
+  bool b3 = e0 + 3 >= st && e0 + 3 < en && h3 <= th;
+  mask = (b0 ? 1u : 0u) | (b1 ? 2u : 0u) | (b2 ? 4u : 0u) | (b3 ? 8u : 0u);
+  hds = h0 | (h1 << 8) | (h2 << 16) | (h3 << 24);
 }
 
-template <bool GT, bool TAP>
+// Scan the listed buckets: G = 2^LOG_G consecutive lanes share one probe and read consecutive
+// aligned 16-byte chunks of its bucket (G*16 contiguous bytes per step); 64/G probes per pass;
+// two chunks per lane in flight.  No search, no prefix sums: the probe of a lane is fixed.
+template <int LOG_G, bool TAP>
+__device__ __forceinline__ void scan_list(const DevIndex& ix, const DevParams& P, const BatchOut& out, const Acc& A,
+                                          WaveState& ws, const ProbeList& pl, uint32_t nact, uint32_t& filt0,
+                                          uint32_t& filt1)
+{
+  constexpr uint32_t G = 1u << LOG_G, PPS = 64u >> LOG_G;
+  const uint32_t lane = lane_id();
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const uint32_t sub = lane & (G - 1u), grp = lane >> LOG_G;
+  for (uint32_t p0 = 0; p0 < nact; p0 += PPS) {
+    const uint32_t pi = p0 + grp;
+    const bool on = pi < nact;
+    const uint64_t b = on ? pl.bkt[pi] : 0ull;
+    const uint32_t q = on ? pl.q[pi] : 0u;
+    const uint32_t tg = on ? pl.tag[pi] : 0u;
+    const uint64_t st = b >> 24;
+    const uint32_t ln = (uint32_t)(b & 0xFFFFFFu);
+    const uint32_t nch = on ? (uint32_t)(((st & 3u) + ln + 3u) >> 2) : 0u;
+    const uint64_t e_al = st & ~3ull;
+    const uint32_t* enc = get_lib(ix, tag_lib(tg)).enc;
+    for (uint32_t c = sub; __ballot(c < nch) != 0; c += 2u * G) {
+      const bool onA = c < nch, onB = c + G < nch;
+      const uint64_t eA = e_al + 4ull * c, eB = eA + 4ull * G;
+      uint4 vA = make_uint4(0, 0, 0, 0), vB = vA;
+      if (onA) vA = *reinterpret_cast<const uint4*>(enc + eA);
+      if (onB) vB = *reinterpret_cast<const uint4*>(enc + eB);
+      uint32_t mA = 0, hA = 0, mB = 0, hB = 0;
+      if (onA) chunk_hits(vA, eA, st, ln, q, P.th, mA, hA);
+      if (onB) chunk_hits(vB, eB, st, ln, q, P.th, mB, hB);
+      // ---- hits -> work stack as unresolved items (their colour is fetched by expand_all)
+      uint32_t pend = mA | (mB << 4);
+      while (__ballot(pend != 0) != 0) {
+        if (ws.top > (uint32_t)(kStackCap - 64)) expand_all<TAP>(ix, out, A, ws);
+        const bool has = pend != 0;
+        const uint32_t bit = has ? (uint32_t)__ffs((int)pend) - 1u : 0u;
+        const uint32_t e = bit & 3u;
+        const uint64_t hm = __ballot(has);
+        if (has) {
+          const uint32_t hd = (((bit >> 2) ? hB : hA) >> (8 * e)) & 31u;
+          const uint64_t idx = ((bit >> 2) ? eB : eA) + e;
+          if (tag_strand(tg))
+            filt1 = min(filt1, hd);
+          else
+            filt0 = min(filt0, hd);
+          ws.stack[ws.top + __popcll(hm & lt)] =
+            make_uint2((uint32_t)idx, tg | (hd << 12) | ((uint32_t)(idx >> 32) << 17) | kItemUnresolved);
+          pend &= pend - 1u;
+        }
+        ws.top += __popcll(hm);
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// fold the planes of one level-1 slot / level-2 slot into its running counts and zero them
+__device__ __forceinline__ void fold_l1(const Acc& A, uint32_t s)
+{
+  uint32_t cum0 = 0, cum1 = 0, cum2 = 0, cum3 = 0;
+  for (uint32_t x = 0; x < A.np; ++x) {
+    uint32_t* p = &A.planes[(s * A.np + x) * kPlaneWords];
+    uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
+    uint32_t add = __popc(w0 & ~cum0) + __popc(w1 & ~cum1) + __popc(w2 & ~cum2) + __popc(w3 & ~cum3);
+    cum0 |= w0, cum1 |= w1, cum2 |= w2, cum3 |= w3;
+    if (w0 | w1 | w2 | w3) p[0] = 0, p[1] = 0, p[2] = 0, p[3] = 0;
+    if (add) A.counts[s * A.np + x] += add;
+  }
+}
+__device__ __forceinline__ void fold_l2(const Acc& A, uint32_t slot2)
+{
+  uint32_t cum0 = 0, cum1 = 0, cum2 = 0, cum3 = 0;
+  for (uint32_t x = 0; x < A.np; ++x) {
+    uint32_t* p = &A.g_planes[((uint64_t)slot2 * A.np + x) * kPlaneWords];
+    uint32_t w0 = gload(p), w1 = gload(p + 1), w2 = gload(p + 2), w3 = gload(p + 3);
+    uint32_t add = __popc(w0 & ~cum0) + __popc(w1 & ~cum1) + __popc(w2 & ~cum2) + __popc(w3 & ~cum3);
+    cum0 |= w0, cum1 |= w1, cum2 |= w2, cum3 |= w3;
+    if (w0) gstore(p, 0);
+    if (w1) gstore(p + 1, 0);
+    if (w2) gstore(p + 2, 0);
+    if (w3) gstore(p + 3, 0);
+    if (add) {
+      uint32_t* cp = &A.g_counts[(uint64_t)slot2 * A.np + x];
+      gstore(cp, gload(cp) + add);
+    }
+  }
+}
+
+// list of touched level-2 slots, ascending (= ascending key); returns its length
+__device__ __forceinline__ uint32_t l2_build_list(const Acc& A)
+{
+  const uint32_t lane = lane_id();
+  uint32_t n = 0;
+  for (uint32_t w0 = 0; w0 < A.bm_words; w0 += 64) {
+    uint32_t wi = w0 + lane;
+    uint32_t word = wi < A.bm_words ? A.bitmap[wi] : 0u;
+    uint32_t c = __popc(word), inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t t = __shfl_up(inc, d);
+      if (lane >= (uint32_t)d) inc += t;
+    }
+    uint32_t o = n + inc - c;
+    while (word) {
+      uint32_t bit = (uint32_t)__ffs((int)word) - 1u;
+      A.g_list[o++] = wi * 32u + bit;
+      word &= word - 1u;
+    }
+    n += __shfl(inc, 63);
+  }
+  __syncthreads();
+  return n;
+}
+
+__device__ __forceinline__ uint32_t hmin_l1(const Acc& A, uint32_t s)
+{
+  for (uint32_t x = 0; x < A.np; ++x)
+    if (A.counts[s * A.np + x]) return x;
+  return 0xFFFFFFFFu;
+}
+__device__ __forceinline__ uint32_t hmin_l2(const Acc& A, uint32_t slot2)
+{
+  for (uint32_t x = 0; x < A.np; ++x)
+    if (gload(&A.g_counts[(uint64_t)slot2 * A.np + x])) return x;
+  return 0xFFFFFFFFu;
+}
+
+// ---------------------------------------------------------------------------
+// One read.
+// ---------------------------------------------------------------------------
+template <int LOG_G, bool TAP>
 __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams& P, const BatchIn& in,
-                                             const BatchOut& out, uint32_t read, const Table<GT>& tb,
-                                             WaveState& ws, const ProbeList& pl)
+                                             const BatchOut& out, uint32_t read, const Acc& A, WaveState& ws,
+                                             const ProbeList& pl)
 {
   const uint32_t lane = lane_id();
   const uint64_t lt = (1ull << lane) - 1ull;
@@ -555,8 +603,9 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   const uint64_t nkm = len >= k ? len - k + 1 : 0; // enmers (src/query.cpp:42)
   uint32_t onmers = 0;
   uint32_t filt0 = 0xFFFFFFFFu, filt1 = 0xFFFFFFFFu;
+  bool l2_any = false; // wave-uniform: some key of this read lives in level 2
   ws.top = 0;
-  ws.overflow = false;
+  ws.l2 = false;
   ws.read = read;
 
   for (uint64_t base0 = 0; base0 < nkm; base0 += kSegPos) {
@@ -576,126 +625,35 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
         onmers += nv;
       }
       // ---- compact the non-empty probes of this group into the LDS list
-      uint32_t len0 = (uint32_t)(cur.b[0] & 0xFFFFFFu), len1 = (uint32_t)(cur.b[1] & 0xFFFFFFu);
-      bool a0 = len0 > 0, a1 = len1 > 0;
-      uint64_t m0 = __ballot(a0), m1 = __ballot(a1);
-      uint32_t n0 = __popcll(m0), nact = n0 + __popcll(m1);
-      uint32_t ch0 = a0 ? (uint32_t)((((cur.b[0] >> 24) & 3u) + len0 + 3u) >> 2) : 0u;
-      uint32_t ch1 = a1 ? (uint32_t)((((cur.b[1] >> 24) & 3u) + len1 + 3u) >> 2) : 0u;
-      // inclusive scans in list order: all strand-0 probes, then all strand-1 probes
-      uint32_t s0 = ch0, s1 = ch1;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t0 = __shfl_up(s0, d), t1 = __shfl_up(s1, d);
-        if (lane >= (uint32_t)d) {
-          s0 += t0;
-          s1 += t1;
-        }
-      }
-      uint32_t tot0 = __shfl(s0, 63), total = tot0 + __shfl(s1, 63);
+      const bool a0 = (cur.b0 & 0xFFFFFFu) != 0, a1 = (cur.b1 & 0xFFFFFFu) != 0;
+      const uint64_t m0 = __ballot(a0), m1 = __ballot(a1);
+      const uint32_t n0 = __popcll(m0), nact = n0 + __popcll(m1);
       if (a0) {
         uint32_t i = __popcll(m0 & lt);
-        pl.bkt[i] = cur.b[0];
-        pl.q[i] = cur.q[0];
-        pl.tag[i] = (64u * pp + lane) | (cur.lib[0] << 8);
-        pl.pre[i] = s0 - ch0;
+        pl.bkt[i] = cur.b0;
+        pl.q[i] = cur.q0;
+        pl.tag[i] = (64u * pp + lane) | (cur.lib0 << 8);
       }
       if (a1) {
         uint32_t i = n0 + __popcll(m1 & lt);
-        pl.bkt[i] = cur.b[1];
-        pl.q[i] = cur.q[1];
-        pl.tag[i] = (64u * pp + lane) | (1u << 7) | (cur.lib[1] << 8);
-        pl.pre[i] = tot0 + s1 - ch1;
+        pl.bkt[i] = cur.b1;
+        pl.q[i] = cur.q1;
+        pl.tag[i] = (64u * pp + lane) | (1u << 7) | (cur.lib1 << 8);
       }
-      if (lane == 0) pl.pre[nact] = total;
       __syncthreads();
-      // ---- scan: lanes flattened over 16-byte chunks of all listed buckets, two chunks per lane
-      for (uint32_t c0 = 0; c0 < total; c0 += 128) {
-        ChunkHits H[2];
-        uint4 v[2];
-        uint64_t st[2];
-        uint32_t ln[2], qq[2];
-        bool on[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          uint32_t c = c0 + 64u * u + lane;
-          on[u] = c < total;
-          H[u].mask = 0, H[u].hds = 0, H[u].e0 = 0, H[u].tag = 0;
-          st[u] = 0, ln[u] = 0, qq[u] = 0;
-          v[u] = make_uint4(0, 0, 0, 0);
-          if (on[u]) {
-            uint32_t pi = find_probe(pl, nact, c);
-            uint64_t b = pl.bkt[pi];
-            st[u] = b >> 24;
-            ln[u] = (uint32_t)(b & 0xFFFFFFu);
-            qq[u] = pl.q[pi];
-            H[u].tag = pl.tag[pi];
-            H[u].e0 = (st[u] & ~3ull) + 4ull * (c - pl.pre[pi]);
-            DevLib L = get_lib(ix, tag_lib(H[u].tag));
-            v[u] = *reinterpret_cast<const uint4*>(L.enc + H[u].e0);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (!on[u]) continue;
-          uint32_t e4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            uint64_t idx = H[u].e0 + e;
-            uint32_t hd = hd_lr32(e4[e], qq[u]);
-            bool hit = idx >= st[u] && idx < st[u] + ln[u] && hd <= P.th;
-            H[u].mask |= hit ? (1u << e) : 0u;
-            H[u].hds |= hit ? (hd << (8 * e)) : 0u;
-          }
-        }
-        // ---- hits -> work stack as unresolved items (their colour is fetched by expand_all)
-        uint32_t pend = H[0].mask | (H[1].mask << 4);
-        while (__ballot(pend != 0) != 0) {
-          if (ws.top > (uint32_t)(kStackCap - 64)) expand_all<GT, TAP>(ix, out, tb, ws);
-          bool has = pend != 0;
-          uint32_t bit = has ? (uint32_t)__ffs((int)pend) - 1u : 0u;
-          uint32_t u = bit >> 2, e = bit & 3u;
-          uint64_t hm = __ballot(has);
-          if (has) {
-            uint32_t hds = u ? H[1].hds : H[0].hds;
-            uint32_t tg = u ? H[1].tag : H[0].tag;
-            uint64_t idx = (u ? H[1].e0 : H[0].e0) + e;
-            uint32_t hd = (hds >> (8 * e)) & 31u;
-            if (tag_strand(tg))
-              filt1 = min(filt1, hd);
-            else
-              filt0 = min(filt0, hd);
-            uint32_t hi = tg | (hd << 12) | ((uint32_t)(idx >> 32) << 17) | kItemUnresolved;
-            ws.stack[ws.top + __popcll(hm & lt)] = make_uint2((uint32_t)idx, hi);
-            pend &= pend - 1u;
-          }
-          ws.top += __popcll(hm);
-          __syncthreads();
-        }
-      }
+      scan_list<LOG_G, TAP>(ix, P, out, A, ws, pl, nact, filt0, filt1);
       __syncthreads();
       cur = nxt;
     }
-    expand_all<GT, TAP>(ix, out, tb, ws);
+    expand_all<TAP>(ix, out, A, ws);
     // ---- fold this segment's planes into running counts (positions of different
     //      segments are distinct, so histograms add)
     __syncthreads();
-    uint32_t nfold = GT ? *tb.ntouched : (tb.mask + 1);
-    for (uint32_t t = lane; t < nfold; t += 64) {
-      uint32_t s = GT ? tb.touched[t] : t;
-      if (!GT && tb.keys[s] == 0) continue;
-      uint32_t cum0 = 0, cum1 = 0, cum2 = 0, cum3 = 0;
-      for (uint32_t x = 0; x < tb.np; ++x) {
-        uint32_t i = (s * tb.np + x) * kPlaneWords;
-        uint32_t w0 = tb.load_plane(i), w1 = tb.load_plane(i + 1), w2 = tb.load_plane(i + 2), w3 = tb.load_plane(i + 3);
-        uint32_t add = __popc(w0 & ~cum0) + __popc(w1 & ~cum1) + __popc(w2 & ~cum2) + __popc(w3 & ~cum3);
-        cum0 |= w0, cum1 |= w1, cum2 |= w2, cum3 |= w3;
-        if (w0) tb.store_plane(i, 0);
-        if (w1) tb.store_plane(i + 1, 0);
-        if (w2) tb.store_plane(i + 2, 0);
-        if (w3) tb.store_plane(i + 3, 0);
-        if (add) tb.store_count(s * tb.np + x, tb.load_count(s * tb.np + x) + add);
-      }
+    if (A.keys[lane]) fold_l1(A, lane); // kLdsSlots == 64: lane t owns slot t
+    l2_any = __ballot(ws.l2) != 0;
+    if (l2_any) {
+      uint32_t n2 = l2_build_list(A);
+      for (uint32_t t = lane; t < n2; t += 64) fold_l2(A, A.g_list[t]);
     }
     __syncthreads();
   }
@@ -706,39 +664,86 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
     filt0 = min(filt0, (uint32_t)__shfl_xor(filt0, d));
     filt1 = min(filt1, (uint32_t)__shfl_xor(filt1, d));
   }
-  bool ovf = __ballot(ws.overflow) != 0;
   if (ws.err && lane == 0) atomicOr(&out.counters[1], ws.err);
   ws.err = 0;
+  // records that pass `hdist_min <= 2*hdist_filt+1` (src/query.cpp:101-106,119), ordered by key so
+  // that the two strands of a leaf are adjacent
+  const uint32_t lim0 = 2u * filt0 + 1u, lim1 = 2u * filt1 + 1u; // u32 wrap keeps "none" = max
 
-  if (ovf && !GT) { // redo this read with the global table
+  if (!l2_any) {
+    // ---- level 1 only: lane t owns slot t
+    const uint32_t key = A.keys[lane];
+    const bool ok = key && hmin_l1(A, lane) <= ((key & 1u) ? lim1 : lim0);
+    uint64_t okm = __ballot(ok);
+    const uint32_t nrec = __popcll(okm);
+    uint32_t rbase = 0;
     if (lane == 0) {
-      uint32_t o = atomicAdd(&out.counters[2], 1u);
-      out.ovf_list[o] = read;
-      out.rd_cnt[read] = 0;
-      out.rd_off[read] = 0;
+      rbase = atomicAdd(&out.counters[0], nrec);
+      if (rbase + nrec > out.rec_cap) {
+        atomicOr(&out.counters[1], kErrRecCap);
+        rbase = 0xFFFFFFFFu;
+      }
+      out.rd_off[read] = rbase == 0xFFFFFFFFu ? 0 : rbase;
+      out.rd_cnt[read] = rbase == 0xFFFFFFFFu ? 0 : nrec;
+      out.rd_onmers[read] = onmers;
+      out.rd_filt[2 * read] = filt0;
+      out.rd_filt[2 * read + 1] = filt1;
     }
-    clear_lds_table(tb);
+    rbase = __shfl(rbase, 0);
+    uint32_t rank = 0; // number of passing keys smaller than mine
+    while (okm) {
+      int u = __ffsll((long long)okm) - 1;
+      uint32_t kb = __shfl(key, u);
+      rank += (kb < key) ? 1u : 0u;
+      okm &= okm - 1;
+    }
+    if (ok && rbase != 0xFFFFFFFFu) {
+      uint32_t ri = rbase + rank;
+      out.rec_read[ri] = read;
+      out.rec_key[ri] = key;
+      for (uint32_t x = 0; x < A.np; ++x) out.rec_hist[(uint64_t)ri * A.np + x] = A.counts[lane * A.np + x];
+    }
+    if (key) { // leave the slot empty for the next read
+      A.keys[lane] = 0;
+      for (uint32_t x = 0; x < A.np; ++x) A.counts[lane * A.np + x] = 0;
+    }
+    __syncthreads();
     return;
   }
-  if (ovf && GT && lane == 0) atomicOr(&out.counters[1], kErrTable);
 
-  // ---- emit records that pass `hdist_min <= 2*hdist_filt+1` (src/query.cpp:101-106,119),
-  //      ordered by key so that the two strands of a leaf are adjacent.
-  const uint32_t lim0 = 2u * filt0 + 1u, lim1 = 2u * filt1 + 1u; // u32 wrap keeps "none" = max
-  uint32_t nslots = GT ? *tb.ntouched : (tb.mask + 1);
+  // ---- level 2 in use: move the level-1 entries over, then emit from the sorted slot list
+  {
+    const uint32_t key = A.keys[lane];
+    if (key) {
+      uint32_t info = ix.node_info[key >> 1];
+      uint32_t slot2 = ((info >> 2) << 1) | (key & 1u);
+      for (uint32_t x = 0; x < A.np; ++x) {
+        uint32_t c = A.counts[lane * A.np + x];
+        if (c) {
+          uint32_t* cp = &A.g_counts[(uint64_t)slot2 * A.np + x];
+          gstore(cp, gload(cp) + c);
+          A.counts[lane * A.np + x] = 0;
+        }
+      }
+      atomicOr(&A.bitmap[slot2 >> 5], 1u << (slot2 & 31));
+      A.keys[lane] = 0;
+    }
+    __syncthreads();
+  }
+  const uint32_t n2 = l2_build_list(A);
   uint32_t nrec = 0;
-  for (uint32_t t0 = 0; t0 < nslots; t0 += 64) {
+  for (uint32_t t0 = 0; t0 < n2; t0 += 64) {
     uint32_t t = t0 + lane;
     bool ok = false;
-    if (t < nslots) {
-      uint32_t s = GT ? tb.touched[t] : t;
-      uint32_t key = tb.load_key(s);
-      if (key) ok = tb.hdist_min(s) <= ((key & 1u) ? lim1 : lim0);
+    if (t < n2) {
+      uint32_t slot2 = A.g_list[t];
+      ok = hmin_l2(A, slot2) <= ((slot2 & 1u) ? lim1 : lim0);
     }
     nrec += __popcll(__ballot(ok));
   }
   uint32_t rbase = 0;
   if (lane == 0) {
+    atomicAdd(&out.counters[2], 1u);
     rbase = atomicAdd(&out.counters[0], nrec);
     if (rbase + nrec > out.rec_cap) {
       atomicOr(&out.counters[1], kErrRecCap);
@@ -751,115 +756,75 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
     out.rd_filt[2 * read + 1] = filt1;
   }
   rbase = __shfl(rbase, 0);
-  // rank of a record = number of passing keys smaller than its own: for every tile of 64 slots,
-  // walk the passing lanes of every tile with a wave-uniform readlane (a handful of steps)
-  for (uint32_t tA = 0; tA < nslots; tA += 64) {
-    uint32_t t = tA + lane;
-    uint32_t sA = 0, keyA = 0;
-    bool okA = false;
-    if (t < nslots) {
-      sA = GT ? tb.touched[t] : t;
-      keyA = tb.load_key(sA);
-      if (keyA) okA = tb.hdist_min(sA) <= ((keyA & 1u) ? lim1 : lim0);
+  uint32_t run = 0;
+  for (uint32_t t0 = 0; t0 < n2; t0 += 64) {
+    uint32_t t = t0 + lane;
+    bool ok = false;
+    uint32_t slot2 = 0;
+    if (t < n2) {
+      slot2 = A.g_list[t];
+      ok = hmin_l2(A, slot2) <= ((slot2 & 1u) ? lim1 : lim0);
     }
-    uint32_t rank = 0;
-    for (uint32_t tB = 0; tB < nslots; tB += 64) {
-      uint32_t keyB = keyA;
-      bool okB = okA;
-      if (tB != tA) {
-        uint32_t u = tB + lane;
-        keyB = 0, okB = false;
-        if (u < nslots) {
-          uint32_t sB = GT ? tb.touched[u] : u;
-          keyB = tb.load_key(sB);
-          if (keyB) okB = tb.hdist_min(sB) <= ((keyB & 1u) ? lim1 : lim0);
-        }
-      }
-      uint64_t mB = __ballot(okB);
-      while (mB) {
-        int u = __ffsll((long long)mB) - 1;
-        uint32_t kb = __shfl(keyB, u);
-        rank += (kb < keyA) ? 1u : 0u;
-        mB &= mB - 1;
-      }
-    }
-    if (okA && rbase != 0xFFFFFFFFu) {
-      uint32_t ri = rbase + rank;
+    uint64_t okm = __ballot(ok);
+    if (ok && rbase != 0xFFFFFFFFu) {
+      uint32_t ri = rbase + run + __popcll(okm & lt);
       out.rec_read[ri] = read;
-      out.rec_key[ri] = keyA;
-      for (uint32_t x = 0; x < tb.np; ++x) out.rec_hist[(uint64_t)ri * tb.np + x] = tb.load_count(sA * tb.np + x);
+      out.rec_key[ri] = (ix.leaf_se[slot2 >> 1] << 1) | (slot2 & 1u);
+      for (uint32_t x = 0; x < A.np; ++x)
+        out.rec_hist[(uint64_t)ri * A.np + x] = gload(&A.g_counts[(uint64_t)slot2 * A.np + x]);
     }
-    if (!GT && keyA) { // LDS table: the owning lane leaves its slot empty for the next read
-      tb.keys[sA] = 0;
-      for (uint32_t x = 0; x < tb.np; ++x) tb.counts[sA * tb.np + x] = 0;
-    }
+    if (t < n2)
+      for (uint32_t x = 0; x < A.np; ++x) gstore(&A.g_counts[(uint64_t)slot2 * A.np + x], 0);
+    run += __popcll(okm);
   }
-  if (!GT) __syncthreads();
-  // ---- global table: clear what this read touched
-  if (GT) {
-    __syncthreads();
-    uint32_t nt = *tb.ntouched;
-    for (uint32_t t = lane; t < nt; t += 64) {
-      uint32_t s = tb.touched[t];
-      tb.store_key(s, 0);
-      for (uint32_t x = 0; x < tb.np; ++x) tb.store_count(s * tb.np + x, 0);
-    }
-    __syncthreads();
-    if (lane == 0) *tb.ntouched = 0;
-    __syncthreads();
-  }
+  for (uint32_t w = lane; w < A.bm_words; w += 64) A.bitmap[w] = 0;
+  __syncthreads();
 }
 
-template <bool GT, bool TAP>
+template <int LOG_G, bool TAP>
 __global__ __launch_bounds__(kWave) void kr_probe_kernel_t(DevIndex ix, DevParams P, BatchIn in, BatchOut out)
 {
   // One carve of dynamic LDS (base is 16-byte aligned: no static __shared__ in front):
-  //   stack | probe list | ntouched | [LDS table: keys, planes, counts]
+  //   stack | probe list | level-1 table (keys, planes, counts) | level-2 bitmap
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   uint2* s_stack = reinterpret_cast<uint2*>(s_dyn);
   uint64_t* s_bkt = reinterpret_cast<uint64_t*>(s_stack + kStackCap);
   uint32_t* s_q = reinterpret_cast<uint32_t*>(s_bkt + kListCap);
   uint32_t* s_tag = s_q + kListCap;
-  uint32_t* s_pre = s_tag + kListCap; // 129 used, 132 reserved
-  uint32_t* s_ntouched_p = s_pre + kListCap + 4;
-  uint32_t* s_tbl = s_ntouched_p + 4;
+  uint32_t* s_tbl = s_tag + kListCap;
 
-  Table<GT> tb;
-  tb.np = P.np;
-  tb.ntouched = s_ntouched_p;
-  if (GT) {
-    uint64_t w = blockIdx.x;
-    tb.keys = out.g_keys + w * out.g_slots;
-    tb.planes = out.g_planes + w * (uint64_t)out.g_slots * P.np * kPlaneWords;
-    tb.counts = out.g_counts + w * (uint64_t)out.g_slots * P.np;
-    tb.touched = out.g_touched + w * out.g_slots;
-    tb.mask = out.g_slots - 1;
-  } else {
-    tb.keys = s_tbl;
-    tb.planes = s_tbl + kLdsSlots;
-    tb.counts = tb.planes + kLdsSlots * P.np * kPlaneWords;
-    tb.touched = nullptr;
-    tb.mask = kLdsSlots - 1;
+  Acc A;
+  A.np = P.np;
+  A.keys = s_tbl;
+  A.planes = A.keys + kLdsSlots;
+  A.counts = A.planes + kLdsSlots * P.np * kPlaneWords;
+  A.bitmap = A.counts + kLdsSlots * P.np;
+  A.nslots2 = out.nslots2;
+  A.bm_words = out.bm_words;
+  const uint64_t w = blockIdx.x;
+  A.g_planes = out.g_planes + w * (uint64_t)out.nslots2 * P.np * kPlaneWords;
+  A.g_counts = out.g_counts + w * (uint64_t)out.nslots2 * P.np;
+  A.g_list = out.g_list + w * (uint64_t)out.nslots2;
+  { // tables start empty; every read leaves them empty again
+    const uint32_t lane = lane_id();
+    A.keys[lane] = 0;
+    for (uint32_t x = 0; x < P.np; ++x) {
+      A.counts[lane * P.np + x] = 0;
+#pragma unroll
+      for (int q = 0; q < kPlaneWords; ++q) A.planes[(lane * P.np + x) * kPlaneWords + q] = 0;
+    }
+    for (uint32_t q = lane; q < A.bm_words; q += 64) A.bitmap[q] = 0;
   }
-  if (threadIdx.x == 0) *s_ntouched_p = 0;
   __syncthreads();
-  clear_lds_table(tb);
   WaveState ws;
   ws.stack = s_stack;
   ws.top = 0;
-  ws.overflow = false;
+  ws.l2 = false;
   ws.err = 0;
   ws.read = 0;
   ws.base0 = 0;
-  ProbeList pl{s_bkt, s_q, s_tag, s_pre};
-
-  if (GT) {
-    uint32_t n = out.counters[2];
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x)
-      process_read<GT, TAP>(ix, P, in, out, out.ovf_list[i], tb, ws, pl);
-  } else {
-    for (uint32_t r = blockIdx.x; r < in.nreads; r += gridDim.x) process_read<GT, TAP>(ix, P, in, out, r, tb, ws, pl);
-  }
+  ProbeList pl{s_bkt, s_q, s_tag};
+  for (uint32_t r = blockIdx.x; r < in.nreads; r += gridDim.x) process_read<LOG_G, TAP>(ix, P, in, out, r, A, ws, pl);
 }
 
 // ---------------------------------------------------------------------------
@@ -1124,10 +1089,10 @@ __global__ void kr_relayout_inc(const uint64_t* inc, uint32_t nrows, uint64_t* b
   } while (0)
 
 // dynamic LDS bytes of the probe kernel: stack + probe list + ntouched (+ table)
-uint32_t probe_lds_bytes(bool global_table, uint32_t np)
+uint32_t probe_lds_bytes(uint32_t np, uint32_t bm_words)
 {
-  uint32_t b = kStackCap * 8 + kListCap * 8 + 2 * kListCap * 4 + (kListCap + 4) * 4 + 16;
-  if (!global_table) b += kLdsSlots * 4 + kLdsSlots * np * kPlaneWords * 4 + kLdsSlots * np * 4;
+  uint32_t b = kStackCap * 8 + kListCap * 8 + 2 * kListCap * 4;
+  b += kLdsSlots * 4 + kLdsSlots * np * kPlaneWords * 4 + kLdsSlots * np * 4 + bm_words * 4;
   return (b + 15u) & ~15u;
 }
 
@@ -1170,6 +1135,7 @@ LlhConst make_llh_const(uint32_t k, uint32_t h, uint32_t th)
 
 struct kr_index {
   int device = 0;
+  uint32_t log_g = 0;           // lanes per probe in the bucket scan = 2^log_g (from the mean bucket length)
   DevIndex dix;
   std::vector<DevLib> hlibs;    // host copy of the device DevLib array
   std::vector<void*> allocs;    // everything to hipFree
@@ -1181,7 +1147,7 @@ struct kr_index {
 namespace {
 
 struct DescHeader {
-  uint32_t magic, k, h, m, nlibs, tree_nnodes;
+  uint32_t magic, k, h, m, nlibs, tree_nnodes, nleaves, log_g;
   uint64_t res_mask;
   uint8_t ppos[32], npos[32];
 };
@@ -1234,10 +1200,16 @@ int alloc_from_desc(kr_index* ix, const DescHeader& H, const std::vector<DescLib
   }
   void* p;
   int rc;
-  uint64_t b = (uint64_t)H.tree_nnodes + 1;
+  uint64_t b = ((uint64_t)H.tree_nnodes + 1) * 4;
   if ((rc = dev_alloc(ix, &p, b))) return rc;
-  ix->dix.kind = (const uint8_t*)p;
+  ix->dix.node_info = (const uint32_t*)p;
   ix->bufs.push_back({p, b});
+  b = (uint64_t)std::max<uint32_t>(1u, H.nleaves) * 4;
+  if ((rc = dev_alloc(ix, &p, b))) return rc;
+  ix->dix.leaf_se = (const uint32_t*)p;
+  ix->bufs.push_back({p, b});
+  ix->dix.nleaves = H.nleaves;
+  ix->log_g = H.log_g;
   b = (uint64_t)H.m * 4;
   if ((rc = dev_alloc(ix, &p, b))) return rc;
   ix->dix.res_lib = (const int32_t*)p;
@@ -1308,6 +1280,25 @@ int kr_index_upload(const kr_index_view* v, int device, uint32_t flags, kr_index
   }
   for (uint32_t q = 0; q < v->m && q < 64; ++q)
     if (res_lib[q] >= 0) H.res_mask |= 1ull << q;
+  std::vector<uint32_t> node_info(v->tree_nnodes + 1, 0), leaf_se;
+  for (uint32_t se = 1; se <= v->tree_nnodes; ++se) {
+    uint32_t kd = v->node_kind[se] & 3u;
+    node_info[se] = kd;
+    if (kd == 1) {
+      node_info[se] |= (uint32_t)leaf_se.size() << 2;
+      leaf_se.push_back(se);
+    }
+  }
+  H.nleaves = (uint32_t)leaf_se.size();
+  if (2ull * H.nleaves > 65536) return kr::fail(KR_ERR_ARG, "kr_index_upload: more than 32768 reference leaves is not supported");
+  { // lanes per probe: a bucket of L entries spans about (L + 4.5) / 4 aligned 16-byte chunks
+    double nk = 0, nr = 0;
+    for (uint32_t i = 0; i < v->nlibs; ++i) nk += (double)v->libs[i].nkmers, nr += (double)v->libs[i].nrows;
+    double mean_len = nr > 0 ? nk / nr : 0; // empty buckets never reach the scan, so this underestimates slightly
+    H.log_g = mean_len <= 3.0 ? 0u : (mean_len <= 20.0 ? 2u : 3u);
+    if (const char* e = getenv("KR_LOG_G")) H.log_g = (uint32_t)atoi(e) > 3 ? 3u : (uint32_t)atoi(e);
+    if (H.log_g == 1) H.log_g = 2;
+  }
   std::unique_ptr<kr_index> ix(new kr_index());
   ix->device = device;
   int rc = alloc_from_desc(ix.get(), H, L);
@@ -1351,7 +1342,8 @@ int kr_index_upload(const kr_index_view* v, int device, uint32_t flags, kr_index
     kr_index_free(ix.release());
     return kr::fail(KR_ERR_FORMAT, "inc-* is not monotone or a bucket exceeds 2^24 entries / 2^40 offset");
   }
-  HIP_TRY(hipMemcpy((void*)ix->dix.kind, v->node_kind, (uint64_t)v->tree_nnodes + 1, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy((void*)ix->dix.node_info, node_info.data(), node_info.size() * 4, hipMemcpyHostToDevice));
+  if (!leaf_se.empty()) HIP_TRY(hipMemcpy((void*)ix->dix.leaf_se, leaf_se.data(), leaf_se.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy((void*)ix->dix.res_lib, res_lib.data(), (uint64_t)v->m * 4, hipMemcpyHostToDevice));
   *out = ix.release();
   return KR_OK;
@@ -1429,7 +1421,7 @@ struct kr_stream {
   uint32_t max_reads = 0;
   uint64_t max_bases = 0;
   uint32_t rec_cap = 0, hit_cap = 0;
-  uint32_t nwaves = 0, ovf_waves = 0;
+  uint32_t nwaves = 0;
   // device
   uint8_t* d_bases = nullptr;
   uint64_t* d_offsets = nullptr;
@@ -1509,12 +1501,10 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   s->max_reads = max_reads, s->max_bases = max_bases;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
-  // resident waves per CU: LDS-limited (160 KiB per CU), VGPR-limited to 5 waves per SIMD
-  uint32_t per_cu = std::min<uint32_t>(20u, 163840u / probe_lds_bytes(false, p->hdist_th + 1));
+  // resident waves per CU: LDS-limited (160 KiB per CU), VGPR-limited to 4 waves per SIMD
+  const uint32_t nslots2 = std::max<uint32_t>(2u, 2u * ix->dix.nleaves), bm_words = (nslots2 + 31) / 32;
+  uint32_t per_cu = std::min<uint32_t>(16u, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words));
   s->nwaves = (uint32_t)prop.multiProcessorCount * std::max<uint32_t>(1u, per_cu);
-  s->ovf_waves = (uint32_t)prop.multiProcessorCount * 2u;
-  uint32_t nleaves2 = 2u * (ix->dix.tree_nnodes + 1);
-  uint32_t g_slots = std::min<uint32_t>(next_pow2(std::max<uint32_t>(256u, 2u * nleaves2)), 1u << 16);
   // default record capacity: up to 2 * leaves per read, at most 16 per read on average
   uint64_t per_read = std::min<uint64_t>(16, std::max<uint64_t>(8, (uint64_t)ix->dix.tree_nnodes + 1));
   uint64_t rc64 = max_records ? max_records : std::max<uint64_t>(1u << 16, (uint64_t)max_reads * per_read);
@@ -1545,17 +1535,15 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   SA(o.rec_v, s->rec_cap);
   SA(o.rec_chisq, s->rec_cap);
   SA(o.rec_sel, s->rec_cap);
-  SA(o.ovf_list, max_reads);
   o.rec_cap = s->rec_cap;
   o.hit_cap = s->hit_cap;
-  o.g_slots = g_slots;
-  SA(o.g_keys, (uint64_t)s->ovf_waves * g_slots);
-  SA(o.g_planes, (uint64_t)s->ovf_waves * g_slots * np * kPlaneWords);
-  SA(o.g_counts, (uint64_t)s->ovf_waves * g_slots * np);
-  SA(o.g_touched, (uint64_t)s->ovf_waves * g_slots);
-  HIP_TRY(hipMemset(o.g_keys, 0, (uint64_t)s->ovf_waves * g_slots * 4));
-  HIP_TRY(hipMemset(o.g_planes, 0, (uint64_t)s->ovf_waves * g_slots * np * kPlaneWords * 4));
-  HIP_TRY(hipMemset(o.g_counts, 0, (uint64_t)s->ovf_waves * g_slots * np * 4));
+  o.nslots2 = nslots2;
+  o.bm_words = bm_words;
+  SA(o.g_planes, (uint64_t)s->nwaves * nslots2 * np * kPlaneWords);
+  SA(o.g_counts, (uint64_t)s->nwaves * nslots2 * np);
+  SA(o.g_list, (uint64_t)s->nwaves * nslots2);
+  HIP_TRY(hipMemset(o.g_planes, 0, (uint64_t)s->nwaves * nslots2 * np * kPlaneWords * 4));
+  HIP_TRY(hipMemset(o.g_counts, 0, (uint64_t)s->nwaves * nslots2 * np * 4));
   HA(s->h_bases, max_bases + 256);
   HA(s->h_offsets, (uint64_t)max_reads + 1);
   HA(s->h_counters, 8);
@@ -1621,13 +1609,24 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
       HIP_TRY(hipHostMalloc((void**)&s->h_hits, (uint64_t)s->hit_cap * sizeof(kr_hit), hipHostMallocDefault));
       s->hallocs.push_back(s->h_hits);
     }
-    hipLaunchKernelGGL((kr_probe_kernel_t<false, true>), dim3(grid), dim3(kWave), probe_lds_bytes(false, s->dp.np), st, dix, s->dp, s->in, s->out);
+  }
+  {
+    const uint32_t lds = probe_lds_bytes(s->dp.np, s->out.bm_words);
+    const bool tap = (flags & KR_TAP_HITS) != 0;
+#define KR_LAUNCH(LG)                                                                                              \
+  do {                                                                                                             \
+    if (tap)                                                                                                       \
+      hipLaunchKernelGGL((kr_probe_kernel_t<LG, true>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out); \
+    else                                                                                                           \
+      hipLaunchKernelGGL((kr_probe_kernel_t<LG, false>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out); \
+  } while (0)
+    switch (s->ix->log_g) {
+      case 0: KR_LAUNCH(0); break;
+      case 2: KR_LAUNCH(2); break;
+      default: KR_LAUNCH(3); break;
+    }
+#undef KR_LAUNCH
     HIP_TRY(hipEventRecord(s->ev[2], st));
-    hipLaunchKernelGGL((kr_probe_kernel_t<true, true>), dim3(s->ovf_waves), dim3(kWave), probe_lds_bytes(true, s->dp.np), st, dix, s->dp, s->in, s->out);
-  } else {
-    hipLaunchKernelGGL((kr_probe_kernel_t<false, false>), dim3(grid), dim3(kWave), probe_lds_bytes(false, s->dp.np), st, dix, s->dp, s->in, s->out);
-    HIP_TRY(hipEventRecord(s->ev[2], st));
-    hipLaunchKernelGGL((kr_probe_kernel_t<true, false>), dim3(s->ovf_waves), dim3(kWave), probe_lds_bytes(true, s->dp.np), st, dix, s->dp, s->in, s->out);
   }
   HIP_TRY(hipEventRecord(s->ev[3], st));
   hipLaunchKernelGGL(kr_llh_kernel, dim3(1024), dim3(256), 0, st, s->llh, dix, s->out);
