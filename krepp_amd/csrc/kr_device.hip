@@ -52,16 +52,18 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kSegPos = 128;      // k-mer positions per segment = 4 plane words
 constexpr int kPlaneWords = kSegPos / 32;
-constexpr int kMaxRuns = 16;
 constexpr int kMaxLibs = 16;
 constexpr int kStackCap = 256;    // colour work stack (items of 8 B)
 constexpr int kLdsSlots = 64;     // level-1 (LDS) accumulator slots per wave: lane t owns slot t in the epilogue
 constexpr int kLdsProbeMax = 8;   // bounded probe sequence of the level-1 table
 constexpr int kMaxPlanes = KR_MAX_HDIST_TH + 1;
 
-struct Runs {
-  uint32_t n;
-  uint8_t src[kMaxRuns], len[kMaxRuns], dst[kMaxRuns];
+// Software PEXT for a fixed 32-bit mask (Hacker's Delight 7-4 "compress"): five precomputed
+// move masks; x86's _pext_u64 in LSHF::compute_hash / drop_ppos_lr (src/lshf.cpp:62-69) becomes
+// 5 x (and, xor, shift, or) with wave-uniform constants held in SGPRs.
+struct PextMask {
+  uint32_t m;
+  uint32_t mv[5];
 };
 
 struct DevLib {
@@ -77,7 +79,7 @@ struct DevLib {
 struct DevIndex {
   uint32_t k, h, m, nlibs, tree_nnodes;
   uint32_t m_shift;      // log2(m) if m is a power of two, else 0xFFFFFFFF
-  Runs prun, nrun;       // contiguous runs of the LSH / non-LSH position lists
+  PextMask pmask, nmask; // bit masks of the LSH / non-LSH positions within the k-bit half-codes
   uint32_t nleaves;
   const uint32_t* node_info; // [tree_nnodes+1] kind (0 null, 1 leaf, 2 internal) | leaf_rank << 2
   const uint32_t* leaf_se;   // [nleaves] colour id of the leaf with a given rank (ranks follow se order)
@@ -138,11 +140,40 @@ struct BatchIn {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
-__device__ __forceinline__ uint32_t pext_runs(uint32_t v, const Runs& r)
+// LDS pointers carry their address space in the type so that every access is a ds_ instruction
+// (a generic pointer that the compiler cannot trace back to LDS becomes a flat_ access, which
+// waits on both the LDS and the vector-memory counters).
+#define KR_LDS __attribute__((address_space(3)))
+typedef KR_LDS uint32_t lds_u32;
+typedef KR_LDS uint64_t lds_u64;
+__device__ __forceinline__ uint32_t lds_cas(lds_u32* p, uint32_t expected, uint32_t desired)
 {
-  uint32_t out = 0;
-  for (uint32_t i = 0; i < r.n; ++i) out |= ((v >> r.src[i]) & ((1u << r.len[i]) - 1u)) << r.dst[i];
-  return out;
+  __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return expected;
+}
+__device__ __forceinline__ void lds_or(lds_u32* p, uint32_t v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t lds_ld(lds_u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// The probe kernel runs one wave64 per workgroup, so LDS hand-offs are between lanes of ONE wave:
+// LDS operations of a wave execute in issue order, and all that is needed is that the compiler
+// keeps that order.  __syncthreads() would also drain every outstanding global load
+// (s_waitcnt vmcnt(0)) and so serialise the prefetched bucket loads behind each LDS exchange.
+#define WAVE_SYNC()                                          \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+
+__device__ __forceinline__ uint32_t pext32(uint32_t x, const PextMask& pm)
+{
+  x &= pm.m;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    uint32_t t = x & pm.mv[i];
+    x = (x ^ t) | (t >> (1 << i));
+  }
+  return x;
 }
 
 // 16 -> 32 bit spread: bit j of v moves to bit 2j
@@ -222,14 +253,15 @@ __device__ __forceinline__ FrontEnd front_end(const DevIndex& ix, const SegBits&
   // position p of the k-mer counts from its LAST base
   uint32_t lo_f = __brev(wl) >> (32 - ix.k), hi_f = __brev(wh) >> (32 - ix.k);
   uint32_t lo_r = ~wl & mk, hi_r = ~wh & mk; // reverse complement: complement, order already reversed
-  fe.rix[0] = spread16(pext_runs(lo_f, ix.prun)) | (spread16(pext_runs(hi_f, ix.prun)) << 1);
-  fe.rix[1] = spread16(pext_runs(lo_r, ix.prun)) | (spread16(pext_runs(hi_r, ix.prun)) << 1);
-  fe.enc32[0] = pext_runs(lo_f, ix.nrun) | (pext_runs(hi_f, ix.nrun) << 16);
-  fe.enc32[1] = pext_runs(lo_r, ix.nrun) | (pext_runs(hi_r, ix.nrun) << 16);
+  fe.rix[0] = spread16(pext32(lo_f, ix.pmask)) | (spread16(pext32(hi_f, ix.pmask)) << 1);
+  fe.rix[1] = spread16(pext32(lo_r, ix.pmask)) | (spread16(pext32(hi_r, ix.pmask)) << 1);
+  fe.enc32[0] = pext32(lo_f, ix.nmask) | (pext32(hi_f, ix.nmask) << 16);
+  fe.enc32[1] = pext32(lo_r, ix.nmask) | (pext32(hi_r, ix.nmask) << 16);
   return fe;
 }
 
 // Index::check_partial + Index::bucket_indices (src/index.hpp:27, src/index.cpp:160-168)
+template <bool SL>
 __device__ __forceinline__ bool locate_row(const DevIndex& ix, uint32_t rix, int& lib, uint32_t& row)
 {
   uint32_t res, q;
@@ -241,7 +273,7 @@ __device__ __forceinline__ bool locate_row(const DevIndex& ix, uint32_t rix, int
     res = rix - q * ix.m;
   }
   uint32_t numer, nrows;
-  if (ix.nlibs == 1 && ix.m <= 64) { // everything from kernel arguments
+  if (SL) { // everything from kernel arguments
     if (!((ix.res_mask >> res) & 1ull)) return false;
     lib = 0;
     numer = ix.lib0.numer;
@@ -265,11 +297,11 @@ __device__ __forceinline__ bool locate_row(const DevIndex& ix, uint32_t rix, int
 // ---------------------------------------------------------------------------
 struct Acc {
   // level 1 (LDS)
-  uint32_t* keys;    // [kLdsSlots]
-  uint32_t* planes;  // [kLdsSlots * np * 4]
-  uint32_t* counts;  // [kLdsSlots * np]
+  lds_u32* keys;    // [kLdsSlots]
+  lds_u32* planes;  // [kLdsSlots * np * 4]
+  lds_u32* counts;  // [kLdsSlots * np]
   // level 2
-  uint32_t* bitmap;   // LDS [bm_words]
+  lds_u32* bitmap;   // LDS [bm_words]
   uint32_t* g_planes; // global [nslots2 * np * 4]
   uint32_t* g_counts; // global [nslots2 * np]
   uint32_t* g_list;   // global [nslots2]
@@ -289,7 +321,7 @@ __device__ __forceinline__ uint32_t tag_lib(uint32_t t) { return (t >> 8) & 15u;
 __device__ __forceinline__ uint32_t tag_hd(uint32_t t) { return (t >> 12) & 31u; }
 
 struct WaveState {
-  uint2* stack;   // LDS [kStackCap]
+  lds_u64* stack;   // LDS [kStackCap]: lo | hi << 32
   uint32_t top;   // wave-uniform
   bool l2;        // this lane sent something to level 2 during this read
   uint32_t err;
@@ -297,54 +329,57 @@ struct WaveState {
   uint32_t base0; // first k-mer position of the current segment
 };
 
+// SL (single library, m <= 64) is a compile-time property of the launched kernel: the library
+// descriptor and the residue mask then come from kernel arguments (SGPRs) with no load at all.
+template <bool SL>
 __device__ __forceinline__ DevLib get_lib(const DevIndex& ix, uint32_t lib)
 {
-  if (ix.nlibs == 1) return ix.lib0; // kernel-argument (SGPR) copy: no dependent load
+  if (SL) return ix.lib0;
   return ix.libs[lib];
 }
 
 // Minfo::update_match (src/query.hpp:153-176) as an idempotent OR: bit `pos` of plane `hd`.
-__device__ __forceinline__ void accumulate(const Acc& A, WaveState& ws, uint32_t se, uint32_t info, uint32_t tag)
+__device__ __forceinline__ void accumulate(const DevIndex& ix, const Acc& A, WaveState& ws, uint32_t se, uint32_t tag)
 {
   const uint32_t key = (se << 1) | tag_strand(tag);
   const uint32_t hd = tag_hd(tag), pos = tag_pos(tag);
   uint32_t s = (hash_key(key) >> 8) & (kLdsSlots - 1);
 #pragma unroll 1
   for (int i = 0; i < kLdsProbeMax; ++i) {
-    uint32_t cur = ((volatile uint32_t*)A.keys)[s];
+    uint32_t cur = lds_ld(&A.keys[s]);
     if (cur == 0) {
-      uint32_t old = atomicCAS(&A.keys[s], 0u, key);
+      uint32_t old = lds_cas(&A.keys[s], 0u, key);
       cur = old == 0 ? key : old;
     }
     if (cur == key) {
-      atomicOr(&A.planes[(s * A.np + hd) * kPlaneWords + (pos >> 5)], 1u << (pos & 31));
+      lds_or(&A.planes[(s * A.np + hd) * kPlaneWords + (pos >> 5)], 1u << (pos & 31));
       return;
     }
     s = (s + 1) & (kLdsSlots - 1);
   }
   // level 2
-  const uint32_t slot2 = ((info >> 2) << 1) | tag_strand(tag);
-  atomicOr(&A.bitmap[slot2 >> 5], 1u << (slot2 & 31));
+  const uint32_t slot2 = ((ix.node_info[se] >> 2) << 1) | tag_strand(tag);
+  lds_or(&A.bitmap[slot2 >> 5], 1u << (slot2 & 31));
   __hip_atomic_fetch_or(&A.g_planes[((uint64_t)slot2 * A.np + hd) * kPlaneWords + (pos >> 5)], 1u << (pos & 31),
                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   ws.l2 = true;
 }
 
-// classify one colour: leaf -> accumulate, null -> drop, anything else -> caller pushes it
-__device__ __forceinline__ bool colour_needs_expansion(const DevIndex& ix, const Acc& A, WaveState& ws, uint32_t se,
+// Colour ids in HBM carry their class in the top two bits (set once at upload, see
+// kr_tag_colours): 0 = drop (empty set / null tree node), 1 = tree leaf, 2 = expand through
+// se_to_pse.  This replaces Tree::check_node + get_node + check_leaf (src/query.cpp:371-381)
+// and a dependent load per colour.
+constexpr uint32_t kColMask = 0x3FFFFFFFu;
+__device__ __forceinline__ bool colour_needs_expansion(const DevIndex& ix, const Acc& A, WaveState& ws, uint32_t tse,
                                                        uint32_t tag)
 {
-  if (se == 0) return false;
-  if (se <= ix.tree_nnodes) { // Tree::check_node (src/phytree.hpp:34)
-    uint32_t info = ix.node_info[se];
-    if ((info & 3u) == 1u) accumulate(A, ws, se, info, tag);
-    return (info & 3u) == 2u;
-  }
-  return true;
+  const uint32_t cls = tse >> 30;
+  if (cls == 1u) accumulate(ix, A, ws, tse & kColMask, tag);
+  return cls == 2u;
 }
 
 // Colour expansion (the BFS of src/query.cpp:369-387, order-free here): drain the work stack.
-template <bool TAP>
+template <bool SL, bool TAP>
 __device__ __forceinline__ void expand_all(const DevIndex& ix, const BatchOut& out, const Acc& A, WaveState& ws)
 {
   const uint32_t lane = lane_id();
@@ -359,13 +394,17 @@ __device__ __forceinline__ void expand_all(const DevIndex& ix, const BatchOut& o
     }
     uint32_t base = ws.top - n;
     bool have = lane < n;
-    uint2 item = have ? ws.stack[base + lane] : make_uint2(0, 0);
+    uint2 item = make_uint2(0, 0);
+    if (have) {
+      uint64_t raw = ws.stack[base + lane];
+      item = make_uint2((uint32_t)raw, (uint32_t)(raw >> 32));
+    }
     ws.top = base;
     uint32_t se = item.x, tag = item.y;
     uint32_t c0 = 0, c1 = 0;
     bool p0 = false, p1 = false;
     if (have) {
-      DevLib L = get_lib(ix, tag_lib(tag));
+      DevLib L = get_lib<SL>(ix, tag_lib(tag));
       if (tag & kItemUnresolved) { // fetch the colour of a fresh hit
         uint64_t idx = (uint64_t)item.x | ((uint64_t)((tag >> 17) & 0xFFu) << 32);
         se = L.se[idx];
@@ -379,7 +418,7 @@ __device__ __forceinline__ void expand_all(const DevIndex& ix, const BatchOut& o
             h.lib = tag_lib(tag);
             h.cmer_index = idx;
             h.hd = tag_hd(tag);
-            h.se = se;
+            h.se = se & kColMask;
             out.hits[hix] = h;
           } else {
             atomicOr(&out.counters[1], kErrHitCap);
@@ -388,7 +427,7 @@ __device__ __forceinline__ void expand_all(const DevIndex& ix, const BatchOut& o
         tag &= 0x1FFFFu;
       }
       if (colour_needs_expansion(ix, A, ws, se, tag)) {
-        uint2 pr = se < L.nsubsets ? L.pse[se] : make_uint2(0, 0);
+        uint2 pr = L.pse[se & kColMask];
         c0 = pr.x;
         c1 = pr.y;
         p0 = colour_needs_expansion(ix, A, ws, c0, tag);
@@ -396,11 +435,11 @@ __device__ __forceinline__ void expand_all(const DevIndex& ix, const BatchOut& o
       }
     }
     uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
-    if (p0) ws.stack[ws.top + __popcll(m0 & lt)] = make_uint2(c0, tag);
+    if (p0) ws.stack[ws.top + __popcll(m0 & lt)] = (uint64_t)c0 | ((uint64_t)tag << 32);
     ws.top += __popcll(m0);
-    if (p1) ws.stack[ws.top + __popcll(m1 & lt)] = make_uint2(c1, tag);
+    if (p1) ws.stack[ws.top + __popcll(m1 & lt)] = (uint64_t)c1 | ((uint64_t)tag << 32);
     ws.top += __popcll(m1);
-    __syncthreads();
+    WAVE_SYNC();
   }
 }
 
@@ -409,9 +448,9 @@ __device__ __forceinline__ void expand_all(const DevIndex& ix, const BatchOut& o
 // ---------------------------------------------------------------------------
 constexpr int kListCap = 128;
 struct ProbeList {
-  uint64_t* bkt; // [128] (start << 24) | len
-  uint32_t* q;   // [128] residual code of the query k-mer
-  uint32_t* tag; // [128] pos | strand<<7 | lib<<8
+  lds_u64* bkt; // [128] (start << 24) | len
+  lds_u32* q;   // [128] residual code of the query k-mer
+  lds_u32* tag; // [128] pos | strand<<7 | lib<<8
 };
 
 struct Cand { // one lane's two candidate probes (forward, reverse) of a position
@@ -421,6 +460,7 @@ struct Cand { // one lane's two candidate probes (forward, reverse) of a positio
 };
 
 // front end + descriptor loads for positions 64*pp + lane
+template <bool SL>
 __device__ __forceinline__ Cand fetch_group(const DevIndex& ix, const SegBits& sb, int pp, uint32_t npos_seg,
                                             uint32_t& nvalid)
 {
@@ -432,13 +472,13 @@ __device__ __forceinline__ Cand fetch_group(const DevIndex& ix, const SegBits& s
   c.b0 = 0, c.b1 = 0, c.lib0 = 0, c.lib1 = 0;
   c.q0 = fe.enc32[0];
   c.q1 = fe.enc32[1];
-  if (fe.valid && locate_row(ix, fe.rix[0], lib, row)) {
+  if (fe.valid && locate_row<SL>(ix, fe.rix[0], lib, row)) {
     c.lib0 = (uint32_t)lib;
-    c.b0 = get_lib(ix, (uint32_t)lib).bkt[row];
+    c.b0 = get_lib<SL>(ix, (uint32_t)lib).bkt[row];
   }
-  if (fe.valid && locate_row(ix, fe.rix[1], lib, row)) {
+  if (fe.valid && locate_row<SL>(ix, fe.rix[1], lib, row)) {
     c.lib1 = (uint32_t)lib;
-    c.b1 = get_lib(ix, (uint32_t)lib).bkt[row];
+    c.b1 = get_lib<SL>(ix, (uint32_t)lib).bkt[row];
   }
   return c;
 }
@@ -459,59 +499,104 @@ __device__ __forceinline__ void chunk_hits(uint4 v, uint64_t e0, uint64_t st, ui
 
 // Scan the listed buckets: G = 2^LOG_G consecutive lanes share one probe and read consecutive
 // aligned 16-byte chunks of its bucket (G*16 contiguous bytes per step); 64/G probes per pass;
-// two chunks per lane in flight.  No search, no prefix sums: the probe of a lane is fixed.
-template <int LOG_G, bool TAP>
+// two chunks per lane per pass, and the loads of the NEXT pass are issued before the current
+// pass is examined (software pipeline: four 16-byte loads in flight per lane).  No search, no
+// prefix sums: the probe of a lane is fixed by its lane id.
+struct ScanStep {
+  uint64_t st, eA;
+  uint32_t ln, q, tg, nch;
+  uint4 vA, vB;
+};
+
+template <int LOG_G, bool SL>
+__device__ __forceinline__ void scan_issue(const DevIndex& ix, const ProbeList& pl, uint32_t nact, uint32_t p0, ScanStep& S)
+{
+  constexpr uint32_t G = 1u << LOG_G;
+  const uint32_t lane = lane_id();
+  const uint32_t sub = lane & (G - 1u), pi = p0 + (lane >> LOG_G);
+  const bool on = pi < nact;
+  const uint64_t b = on ? pl.bkt[pi] : 0ull;
+  S.q = on ? pl.q[pi] : 0u;
+  S.tg = on ? pl.tag[pi] : 0u;
+  S.st = b >> 24;
+  S.ln = (uint32_t)(b & 0xFFFFFFu);
+  S.nch = on ? (uint32_t)(((S.st & 3u) + S.ln + 3u) >> 2) : 0u;
+  S.eA = (S.st & ~3ull) + 4ull * sub;
+  S.vA = make_uint4(0, 0, 0, 0);
+  S.vB = S.vA;
+  const uint32_t* enc = get_lib<SL>(ix, tag_lib(S.tg)).enc;
+  if (sub < S.nch) S.vA = *reinterpret_cast<const uint4*>(enc + S.eA);
+  if (sub + G < S.nch) S.vB = *reinterpret_cast<const uint4*>(enc + S.eA + 4ull * G);
+}
+
+// push the hits of two chunks (A at entry eA, B at entry eB) as unresolved work items
+template <bool SL, bool TAP>
+__device__ __forceinline__ void push_hits(const DevIndex& ix, const BatchOut& out, const Acc& A, WaveState& ws, uint32_t tg,
+                                          uint64_t eA, uint64_t eB, uint32_t mA, uint32_t hA, uint32_t mB, uint32_t hB,
+                                          uint32_t& filt0, uint32_t& filt1)
+{
+  const uint32_t lane = lane_id();
+  const uint64_t lt = (1ull << lane) - 1ull;
+  uint32_t pend = mA | (mB << 4);
+  while (__ballot(pend != 0) != 0) {
+    if (ws.top > (uint32_t)(kStackCap - 64)) expand_all<SL, TAP>(ix, out, A, ws);
+    const bool has = pend != 0;
+    const uint32_t bit = has ? (uint32_t)__ffs((int)pend) - 1u : 0u;
+    const uint32_t e = bit & 3u;
+    const uint64_t hm = __ballot(has);
+    if (has) {
+      const uint32_t hd = (((bit >> 2) ? hB : hA) >> (8 * e)) & 31u;
+      const uint64_t idx = ((bit >> 2) ? eB : eA) + e;
+      if (tag_strand(tg))
+        filt1 = min(filt1, hd);
+      else
+        filt0 = min(filt0, hd);
+      ws.stack[ws.top + __popcll(hm & lt)] =
+        (uint64_t)(uint32_t)idx | ((uint64_t)(tg | (hd << 12) | ((uint32_t)(idx >> 32) << 17) | kItemUnresolved) << 32);
+      pend &= pend - 1u;
+    }
+    ws.top += __popcll(hm);
+    WAVE_SYNC();
+  }
+}
+
+template <int LOG_G, bool SL, bool TAP>
 __device__ __forceinline__ void scan_list(const DevIndex& ix, const DevParams& P, const BatchOut& out, const Acc& A,
                                           WaveState& ws, const ProbeList& pl, uint32_t nact, uint32_t& filt0,
                                           uint32_t& filt1)
 {
   constexpr uint32_t G = 1u << LOG_G, PPS = 64u >> LOG_G;
-  const uint32_t lane = lane_id();
-  const uint64_t lt = (1ull << lane) - 1ull;
-  const uint32_t sub = lane & (G - 1u), grp = lane >> LOG_G;
+  const uint32_t sub = lane_id() & (G - 1u);
+  if (nact == 0) return;
+  ScanStep cur, nxt;
+  scan_issue<LOG_G, SL>(ix, pl, nact, 0, cur);
   for (uint32_t p0 = 0; p0 < nact; p0 += PPS) {
-    const uint32_t pi = p0 + grp;
-    const bool on = pi < nact;
-    const uint64_t b = on ? pl.bkt[pi] : 0ull;
-    const uint32_t q = on ? pl.q[pi] : 0u;
-    const uint32_t tg = on ? pl.tag[pi] : 0u;
-    const uint64_t st = b >> 24;
-    const uint32_t ln = (uint32_t)(b & 0xFFFFFFu);
-    const uint32_t nch = on ? (uint32_t)(((st & 3u) + ln + 3u) >> 2) : 0u;
-    const uint64_t e_al = st & ~3ull;
-    const uint32_t* enc = get_lib(ix, tag_lib(tg)).enc;
-    for (uint32_t c = sub; __ballot(c < nch) != 0; c += 2u * G) {
-      const bool onA = c < nch, onB = c + G < nch;
-      const uint64_t eA = e_al + 4ull * c, eB = eA + 4ull * G;
-      uint4 vA = make_uint4(0, 0, 0, 0), vB = vA;
-      if (onA) vA = *reinterpret_cast<const uint4*>(enc + eA);
-      if (onB) vB = *reinterpret_cast<const uint4*>(enc + eB);
+    nxt = cur;
+    if (p0 + PPS < nact) scan_issue<LOG_G, SL>(ix, pl, nact, p0 + PPS, nxt);
+    // ---- first two chunks of every probe of this pass (already loaded)
+    {
       uint32_t mA = 0, hA = 0, mB = 0, hB = 0;
-      if (onA) chunk_hits(vA, eA, st, ln, q, P.th, mA, hA);
-      if (onB) chunk_hits(vB, eB, st, ln, q, P.th, mB, hB);
-      // ---- hits -> work stack as unresolved items (their colour is fetched by expand_all)
-      uint32_t pend = mA | (mB << 4);
-      while (__ballot(pend != 0) != 0) {
-        if (ws.top > (uint32_t)(kStackCap - 64)) expand_all<TAP>(ix, out, A, ws);
-        const bool has = pend != 0;
-        const uint32_t bit = has ? (uint32_t)__ffs((int)pend) - 1u : 0u;
-        const uint32_t e = bit & 3u;
-        const uint64_t hm = __ballot(has);
-        if (has) {
-          const uint32_t hd = (((bit >> 2) ? hB : hA) >> (8 * e)) & 31u;
-          const uint64_t idx = ((bit >> 2) ? eB : eA) + e;
-          if (tag_strand(tg))
-            filt1 = min(filt1, hd);
-          else
-            filt0 = min(filt0, hd);
-          ws.stack[ws.top + __popcll(hm & lt)] =
-            make_uint2((uint32_t)idx, tg | (hd << 12) | ((uint32_t)(idx >> 32) << 17) | kItemUnresolved);
-          pend &= pend - 1u;
-        }
-        ws.top += __popcll(hm);
-        __syncthreads();
+      const uint64_t eB = cur.eA + 4ull * G;
+      if (sub < cur.nch) chunk_hits(cur.vA, cur.eA, cur.st, cur.ln, cur.q, P.th, mA, hA);
+      if (sub + G < cur.nch) chunk_hits(cur.vB, eB, cur.st, cur.ln, cur.q, P.th, mB, hB);
+      push_hits<SL, TAP>(ix, out, A, ws, cur.tg, cur.eA, eB, mA, hA, mB, hB, filt0, filt1);
+    }
+    // ---- buckets longer than 2*G chunks: the rest, two chunks per lane at a time
+    if (__ballot(cur.nch > 2u * G) != 0) {
+      const uint32_t* enc = get_lib<SL>(ix, tag_lib(cur.tg)).enc;
+      for (uint32_t c = sub + 2u * G; __ballot(c < cur.nch) != 0; c += 2u * G) {
+        const bool onA = c < cur.nch, onB = c + G < cur.nch;
+        const uint64_t eA = (cur.st & ~3ull) + 4ull * c, eB = eA + 4ull * G;
+        uint4 vA = make_uint4(0, 0, 0, 0), vB = vA;
+        if (onA) vA = *reinterpret_cast<const uint4*>(enc + eA);
+        if (onB) vB = *reinterpret_cast<const uint4*>(enc + eB);
+        uint32_t mA = 0, hA = 0, mB = 0, hB = 0;
+        if (onA) chunk_hits(vA, eA, cur.st, cur.ln, cur.q, P.th, mA, hA);
+        if (onB) chunk_hits(vB, eB, cur.st, cur.ln, cur.q, P.th, mB, hB);
+        push_hits<SL, TAP>(ix, out, A, ws, cur.tg, eA, eB, mA, hA, mB, hB, filt0, filt1);
       }
     }
+    cur = nxt;
   }
 }
 
@@ -520,7 +605,7 @@ __device__ __forceinline__ void fold_l1(const Acc& A, uint32_t s)
 {
   uint32_t cum0 = 0, cum1 = 0, cum2 = 0, cum3 = 0;
   for (uint32_t x = 0; x < A.np; ++x) {
-    uint32_t* p = &A.planes[(s * A.np + x) * kPlaneWords];
+    lds_u32* p = &A.planes[(s * A.np + x) * kPlaneWords];
     uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
     uint32_t add = __popc(w0 & ~cum0) + __popc(w1 & ~cum1) + __popc(w2 & ~cum2) + __popc(w3 & ~cum3);
     cum0 |= w0, cum1 |= w1, cum2 |= w2, cum3 |= w3;
@@ -589,7 +674,7 @@ __device__ __forceinline__ uint32_t hmin_l2(const Acc& A, uint32_t slot2)
 // ---------------------------------------------------------------------------
 // One read.
 // ---------------------------------------------------------------------------
-template <int LOG_G, bool TAP>
+template <int LOG_G, bool SL, bool TAP>
 __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams& P, const BatchIn& in,
                                              const BatchOut& out, uint32_t read, const Acc& A, WaveState& ws,
                                              const ProbeList& pl)
@@ -614,14 +699,14 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
     SegBits sb;
     load_segment(seq, len, base0, sb);
     uint32_t nv = 0;
-    Cand cur = fetch_group(ix, sb, 0, npos_seg, nv);
+    Cand cur = fetch_group<SL>(ix, sb, 0, npos_seg, nv);
     onmers += nv;
     const int ngroups = npos_seg > 64 ? 2 : 1;
     for (int pp = 0; pp < ngroups; ++pp) {
       // descriptors of the NEXT group are requested before this group is scanned
       Cand nxt = cur;
       if (pp + 1 < ngroups) {
-        nxt = fetch_group(ix, sb, pp + 1, npos_seg, nv);
+        nxt = fetch_group<SL>(ix, sb, pp + 1, npos_seg, nv);
         onmers += nv;
       }
       // ---- compact the non-empty probes of this group into the LDS list
@@ -640,15 +725,15 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
         pl.q[i] = cur.q1;
         pl.tag[i] = (64u * pp + lane) | (1u << 7) | (cur.lib1 << 8);
       }
-      __syncthreads();
-      scan_list<LOG_G, TAP>(ix, P, out, A, ws, pl, nact, filt0, filt1);
-      __syncthreads();
+      WAVE_SYNC();
+      scan_list<LOG_G, SL, TAP>(ix, P, out, A, ws, pl, nact, filt0, filt1);
+      WAVE_SYNC();
       cur = nxt;
     }
-    expand_all<TAP>(ix, out, A, ws);
+    expand_all<SL, TAP>(ix, out, A, ws);
     // ---- fold this segment's planes into running counts (positions of different
     //      segments are distinct, so histograms add)
-    __syncthreads();
+    WAVE_SYNC();
     if (A.keys[lane]) fold_l1(A, lane); // kLdsSlots == 64: lane t owns slot t
     l2_any = __ballot(ws.l2) != 0;
     if (l2_any) {
@@ -707,7 +792,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
       A.keys[lane] = 0;
       for (uint32_t x = 0; x < A.np; ++x) A.counts[lane * A.np + x] = 0;
     }
-    __syncthreads();
+    WAVE_SYNC();
     return;
   }
 
@@ -725,7 +810,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
           A.counts[lane * A.np + x] = 0;
         }
       }
-      atomicOr(&A.bitmap[slot2 >> 5], 1u << (slot2 & 31));
+      lds_or(&A.bitmap[slot2 >> 5], 1u << (slot2 & 31));
       A.keys[lane] = 0;
     }
     __syncthreads();
@@ -781,17 +866,18 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   __syncthreads();
 }
 
-template <int LOG_G, bool TAP>
+template <int LOG_G, bool SL, bool TAP>
 __global__ __launch_bounds__(kWave) void kr_probe_kernel_t(DevIndex ix, DevParams P, BatchIn in, BatchOut out)
 {
   // One carve of dynamic LDS (base is 16-byte aligned: no static __shared__ in front):
   //   stack | probe list | level-1 table (keys, planes, counts) | level-2 bitmap
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
-  uint2* s_stack = reinterpret_cast<uint2*>(s_dyn);
-  uint64_t* s_bkt = reinterpret_cast<uint64_t*>(s_stack + kStackCap);
-  uint32_t* s_q = reinterpret_cast<uint32_t*>(s_bkt + kListCap);
-  uint32_t* s_tag = s_q + kListCap;
-  uint32_t* s_tbl = s_tag + kListCap;
+  KR_LDS uint8_t* s_base = (KR_LDS uint8_t*)s_dyn;
+  lds_u64* s_stack = (lds_u64*)s_base;
+  lds_u64* s_bkt = (lds_u64*)(s_base + kStackCap * 8);
+  lds_u32* s_q = (lds_u32*)(s_base + kStackCap * 8 + kListCap * 8);
+  lds_u32* s_tag = s_q + kListCap;
+  lds_u32* s_tbl = s_tag + kListCap;
 
   Acc A;
   A.np = P.np;
@@ -824,7 +910,7 @@ __global__ __launch_bounds__(kWave) void kr_probe_kernel_t(DevIndex ix, DevParam
   ws.read = 0;
   ws.base0 = 0;
   ProbeList pl{s_bkt, s_q, s_tag};
-  for (uint32_t r = blockIdx.x; r < in.nreads; r += gridDim.x) process_read<LOG_G, TAP>(ix, P, in, out, r, A, ws, pl);
+  for (uint32_t r = blockIdx.x; r < in.nreads; r += gridDim.x) process_read<LOG_G, SL, TAP>(ix, P, in, out, r, A, ws, pl);
 }
 
 // ---------------------------------------------------------------------------
@@ -1040,7 +1126,7 @@ __global__ __launch_bounds__(kWave) void kr_front_end_kernel(DevIndex ix, BatchI
             rix[o] = fe.rix[s];
             enc32[o] = fe.enc32[s];
             valid[o] = fe.valid;
-            pass[o] = fe.valid && locate_row(ix, fe.rix[s], lib, row);
+            pass[o] = fe.valid && locate_row<false>(ix, fe.rix[s], lib, row);
           }
         }
       }
@@ -1059,12 +1145,30 @@ __global__ void kr_brent_kernel(LlhConst C, uint32_t n, const uint32_t* hist, co
 }
 
 // Re-layout kernels used by kr_index_upload.
-__global__ void kr_relayout_cmer(const uint32_t* cmer, uint64_t n, uint32_t* enc, uint32_t* se)
+// class of a colour id: 0 drop, 1 leaf, 2 expand (see colour_needs_expansion)
+__device__ __forceinline__ uint32_t tag_colour(uint32_t se, const uint32_t* node_info, uint32_t tree_nnodes, uint32_t nsubsets)
+{
+  if (se == 0 || se >= nsubsets || se > kColMask) return 0; // empty set, or an id the crecord does not define
+  if (se <= tree_nnodes) {
+    uint32_t kd = node_info[se] & 3u;
+    return kd ? (se | (kd << 30)) : 0u;
+  }
+  return se | (2u << 30);
+}
+__global__ void kr_relayout_cmer(const uint32_t* cmer, uint64_t n, uint32_t* enc, uint32_t* se, const uint32_t* node_info,
+                                 uint32_t tree_nnodes, uint32_t nsubsets)
 {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     uint2 v = reinterpret_cast<const uint2*>(cmer)[i];
     enc[i] = v.x;
-    se[i] = v.y;
+    se[i] = tag_colour(v.y, node_info, tree_nnodes, nsubsets);
+  }
+}
+__global__ void kr_tag_colours(uint2* pse, uint32_t nsubsets, const uint32_t* node_info, uint32_t tree_nnodes)
+{
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nsubsets; i += gridDim.x * blockDim.x) {
+    uint2 v = pse[i];
+    pse[i] = make_uint2(tag_colour(v.x, node_info, tree_nnodes, nsubsets), tag_colour(v.y, node_info, tree_nnodes, nsubsets));
   }
 }
 __global__ void kr_relayout_inc(const uint64_t* inc, uint32_t nrows, uint64_t* bkt, uint32_t* bad)
@@ -1096,21 +1200,25 @@ uint32_t probe_lds_bytes(uint32_t np, uint32_t bm_words)
   return (b + 15u) & ~15u;
 }
 
-Runs make_runs(const std::vector<uint8_t>& asc)
+PextMask make_pext(const std::vector<uint8_t>& positions)
 {
-  Runs r;
-  memset(&r, 0, sizeof(r));
-  size_t i = 0;
-  while (i < asc.size()) {
-    size_t j = i + 1;
-    while (j < asc.size() && asc[j] == asc[j - 1] + 1) ++j;
-    r.src[r.n] = asc[i];
-    r.len[r.n] = (uint8_t)(j - i);
-    r.dst[r.n] = (uint8_t)i;
-    r.n++;
-    i = j;
+  PextMask pm;
+  uint32_t m = 0;
+  for (uint8_t p : positions) m |= 1u << p;
+  pm.m = m;
+  uint32_t mk = ~m << 1; // count the 0s to the right of every bit
+  for (int i = 0; i < 5; ++i) {
+    uint32_t mp = mk ^ (mk << 1); // parallel suffix
+    mp ^= mp << 2;
+    mp ^= mp << 4;
+    mp ^= mp << 8;
+    mp ^= mp << 16;
+    uint32_t mv = mp & m; // bits to move by 2^i
+    pm.mv[i] = mv;
+    m = (m ^ mv) | (mv >> (1 << i));
+    mk &= ~mp;
   }
-  return r;
+  return pm;
 }
 
 LlhConst make_llh_const(uint32_t k, uint32_t h, uint32_t th)
@@ -1229,10 +1337,8 @@ int alloc_from_desc(kr_index* ix, const DescHeader& H, const std::vector<DescLib
     ix->dix.m_shift = s;
   }
   std::vector<uint8_t> pasc(H.ppos, H.ppos + H.h), nasc(H.npos, H.npos + (H.k - H.h));
-  std::sort(pasc.begin(), pasc.end());
-  std::sort(nasc.begin(), nasc.end());
-  ix->dix.prun = make_runs(pasc);
-  ix->dix.nrun = make_runs(nasc);
+  ix->dix.pmask = make_pext(pasc);
+  ix->dix.nmask = make_pext(nasc);
   ix->desc.resize(sizeof(DescHeader) + L.size() * sizeof(DescLib));
   memcpy(ix->desc.data(), &H, sizeof(H));
   memcpy(ix->desc.data() + sizeof(H), L.data(), L.size() * sizeof(DescLib));
@@ -1307,6 +1413,8 @@ int kr_index_upload(const kr_index_view* v, int device, uint32_t flags, kr_index
     return rc;
   }
   const hipMemcpyKind kind = (flags & KR_VIEW_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIP_TRY(hipMemcpy((void*)ix->dix.node_info, node_info.data(), node_info.size() * 4, hipMemcpyHostToDevice));
+  if (!leaf_se.empty()) HIP_TRY(hipMemcpy((void*)ix->dix.leaf_se, leaf_se.data(), leaf_se.size() * 4, hipMemcpyHostToDevice));
   uint32_t* d_bad = nullptr;
   HIP_TRY(hipMalloc(&d_bad, 4));
   HIP_TRY(hipMemset(d_bad, 0, 4));
@@ -1327,12 +1435,17 @@ int kr_index_upload(const kr_index_view* v, int device, uint32_t flags, kr_index
     }
     HIP_TRY(hipMemset((void*)d.enc, 0xFF, (d.nkmers + 16) * 4));
     HIP_TRY(hipMemset((void*)d.se, 0, (d.nkmers + 16) * 4));
-    if (lv.nkmers) hipLaunchKernelGGL(kr_relayout_cmer, dim3(2048), dim3(256), 0, 0, src_cmer, lv.nkmers, (uint32_t*)d.enc, (uint32_t*)d.se);
+    if (lv.nsubsets > kColMask) return kr::fail(KR_ERR_ARG, "kr_index_upload: more than 2^30 colours is not supported");
+    if (lv.nkmers)
+      hipLaunchKernelGGL(kr_relayout_cmer, dim3(2048), dim3(256), 0, 0, src_cmer, lv.nkmers, (uint32_t*)d.enc, (uint32_t*)d.se,
+                         ix->dix.node_info, v->tree_nnodes, lv.nsubsets);
     if (lv.nrows) hipLaunchKernelGGL(kr_relayout_inc, dim3(1024), dim3(256), 0, 0, src_inc, lv.nrows, (uint64_t*)d.bkt, d_bad);
     HIP_TRY(hipDeviceSynchronize());
     if (t_cmer) hipFree(t_cmer);
     if (t_inc) hipFree(t_inc);
     HIP_TRY(hipMemcpy((void*)d.pse, lv.pse, (uint64_t)lv.nsubsets * 8, kind));
+    if (lv.nsubsets) hipLaunchKernelGGL(kr_tag_colours, dim3(1024), dim3(256), 0, 0, (uint2*)d.pse, lv.nsubsets, ix->dix.node_info, v->tree_nnodes);
+    HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy((void*)d.rho, lv.rho, (uint64_t)lv.nnodes * 8, kind));
   }
   uint32_t bad = 0;
@@ -1342,8 +1455,6 @@ int kr_index_upload(const kr_index_view* v, int device, uint32_t flags, kr_index
     kr_index_free(ix.release());
     return kr::fail(KR_ERR_FORMAT, "inc-* is not monotone or a bucket exceeds 2^24 entries / 2^40 offset");
   }
-  HIP_TRY(hipMemcpy((void*)ix->dix.node_info, node_info.data(), node_info.size() * 4, hipMemcpyHostToDevice));
-  if (!leaf_se.empty()) HIP_TRY(hipMemcpy((void*)ix->dix.leaf_se, leaf_se.data(), leaf_se.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy((void*)ix->dix.res_lib, res_lib.data(), (uint64_t)v->m * 4, hipMemcpyHostToDevice));
   *out = ix.release();
   return KR_OK;
@@ -1613,18 +1724,27 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
   {
     const uint32_t lds = probe_lds_bytes(s->dp.np, s->out.bm_words);
     const bool tap = (flags & KR_TAP_HITS) != 0;
-#define KR_LAUNCH(LG)                                                                                              \
-  do {                                                                                                             \
-    if (tap)                                                                                                       \
-      hipLaunchKernelGGL((kr_probe_kernel_t<LG, true>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out); \
-    else                                                                                                           \
-      hipLaunchKernelGGL((kr_probe_kernel_t<LG, false>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out); \
+#define KR_LAUNCH2(LG, SLV)                                                                                             \
+  do {                                                                                                                 \
+    if (tap)                                                                                                           \
+      hipLaunchKernelGGL((kr_probe_kernel_t<LG, SLV, true>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out); \
+    else                                                                                                               \
+      hipLaunchKernelGGL((kr_probe_kernel_t<LG, SLV, false>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out); \
   } while (0)
+#define KR_LAUNCH(LG)          \
+  do {                         \
+    if (single)                \
+      KR_LAUNCH2(LG, true);    \
+    else                       \
+      KR_LAUNCH2(LG, false);   \
+  } while (0)
+    const bool single = dix.nlibs == 1 && dix.m <= 64;
     switch (s->ix->log_g) {
       case 0: KR_LAUNCH(0); break;
       case 2: KR_LAUNCH(2); break;
       default: KR_LAUNCH(3); break;
     }
+#undef KR_LAUNCH2
 #undef KR_LAUNCH
     HIP_TRY(hipEventRecord(s->ev[2], st));
   }
