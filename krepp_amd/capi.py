@@ -308,16 +308,24 @@ class Result:
         self.read_cnt = _np(rv.read_cnt, n, np.uint32)
         self.read_onmers = _np(rv.read_onmers, n, np.uint32)
         self.read_na = _np(rv.read_na, n, np.uint8)
-        self.rec_key = _np(rv.rec_key, c, np.uint32)
-        self.rec_sel = _np(rv.rec_sel, c, np.uint8)
-        self.rec_d = _np(rv.rec_d, c, np.float64)
-        self.rec_v = _np(rv.rec_v, c, np.float64)
-        self.rec_chisq = _np(rv.rec_chisq, c, np.float64)
-        self.rec_hist = _np(rv.rec_hist, c * np_planes, np.uint32).reshape(-1, np_planes) if copy_hist and rv.rec_hist else None
-        # read index of every record
-        self.rec_read = np.zeros(c, np.uint32)
+        key = _np(rv.rec_key, c, np.uint32)
+        keep = key != 0  # record slots are handed out in per-wave chunks; key 0 marks an unused slot
+        self.rec_key = key[keep]
+        self.rec_sel = _np(rv.rec_sel, c, np.uint8)[keep]
+        self.rec_d = _np(rv.rec_d, c, np.float64)[keep]
+        self.rec_v = _np(rv.rec_v, c, np.float64)[keep]
+        self.rec_chisq = _np(rv.rec_chisq, c, np.float64)[keep]
+        self.rec_hist = (_np(rv.rec_hist, c * np_planes, np.uint32).reshape(-1, np_planes)[keep]
+                         if copy_hist and rv.rec_hist else None)
+        # read index of every record, and offsets into the compacted arrays
+        rr = np.zeros(c, np.uint32)
         for r in np.nonzero(self.read_cnt)[0]:
-            self.rec_read[self.read_off[r]:self.read_off[r] + self.read_cnt[r]] = r
+            rr[self.read_off[r]:self.read_off[r] + self.read_cnt[r]] = r
+        self.rec_read = rr[keep]
+        newpos = np.cumsum(keep) - 1
+        nz = self.read_cnt > 0
+        self.read_off = np.where(nz, newpos[np.minimum(self.read_off, max(c - 1, 0))] if c else 0, 0).astype(np.uint32)
+        self.nrecs = int(keep.sum())
 
     def rows(self):
         """Sorted list of (read, se, d) output rows — `krepp dist` rows as a set."""

@@ -103,7 +103,7 @@ struct DevParams {
 
 // Everything the kernels write for one batch.
 struct BatchOut {
-  uint32_t* counters;    // [0] nrec  [1] error flags  [2] reads that used level 2  [3] nhits(tap)
+  uint32_t* counters;    // [0] record slots handed out  [1] error flags  [2] reads that used level 2  [3] nhits(tap)  [4] records
   uint32_t* rd_off;
   uint32_t* rd_cnt;
   uint32_t* rd_onmers;
@@ -327,6 +327,9 @@ struct WaveState {
   uint32_t err;
   uint32_t read;  // for the hit tap
   uint32_t base0; // first k-mer position of the current segment
+  uint32_t rec_next, rec_end; // wave-private range of record slots (wave-uniform)
+  uint32_t n_l2;              // reads of this wave that used level 2
+  uint32_t n_rec;             // records this wave emitted
 };
 
 // SL (single library, m <= 64) is a compile-time property of the launched kernel: the library
@@ -671,6 +674,30 @@ __device__ __forceinline__ uint32_t hmin_l2(const Acc& A, uint32_t slot2)
   return 0xFFFFFFFFu;
 }
 
+// Record slots are handed out in wave-private chunks: one returning atomic on the shared counter
+// per ~1000 records instead of one per read (a single word sustains only ~90 M atomics/s chip-wide,
+// which is the read rate of the small-index configuration).  Unused slots at the end of a chunk stay
+// zero (key 0 = hole; the record arrays are zeroed per batch).
+constexpr uint32_t kRecChunk = 256;
+__device__ __forceinline__ uint32_t alloc_records(const BatchOut& out, WaveState& ws, uint32_t n)
+{
+  if (ws.rec_next + n > ws.rec_end) {
+    uint32_t chunk = max(n, kRecChunk), base = 0;
+    if (lane_id() == 0) base = atomicAdd(&out.counters[0], chunk);
+    base = __shfl(base, 0);
+    if ((uint64_t)base + chunk > out.rec_cap) {
+      if (lane_id() == 0) atomicOr(&out.counters[1], kErrRecCap);
+      return 0xFFFFFFFFu;
+    }
+    ws.rec_next = base;
+    ws.rec_end = base + chunk;
+  }
+  uint32_t r = ws.rec_next;
+  ws.rec_next += n;
+  ws.n_rec += n;
+  return r;
+}
+
 // ---------------------------------------------------------------------------
 // One read.
 // ---------------------------------------------------------------------------
@@ -761,20 +788,14 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
     const bool ok = key && hmin_l1(A, lane) <= ((key & 1u) ? lim1 : lim0);
     uint64_t okm = __ballot(ok);
     const uint32_t nrec = __popcll(okm);
-    uint32_t rbase = 0;
+    const uint32_t rbase = nrec ? alloc_records(out, ws, nrec) : 0u;
     if (lane == 0) {
-      rbase = atomicAdd(&out.counters[0], nrec);
-      if (rbase + nrec > out.rec_cap) {
-        atomicOr(&out.counters[1], kErrRecCap);
-        rbase = 0xFFFFFFFFu;
-      }
       out.rd_off[read] = rbase == 0xFFFFFFFFu ? 0 : rbase;
       out.rd_cnt[read] = rbase == 0xFFFFFFFFu ? 0 : nrec;
       out.rd_onmers[read] = onmers;
       out.rd_filt[2 * read] = filt0;
       out.rd_filt[2 * read + 1] = filt1;
     }
-    rbase = __shfl(rbase, 0);
     uint32_t rank = 0; // number of passing keys smaller than mine
     while (okm) {
       int u = __ffsll((long long)okm) - 1;
@@ -826,21 +847,15 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
     }
     nrec += __popcll(__ballot(ok));
   }
-  uint32_t rbase = 0;
+  ws.n_l2++;
+  const uint32_t rbase = nrec ? alloc_records(out, ws, nrec) : 0u;
   if (lane == 0) {
-    atomicAdd(&out.counters[2], 1u);
-    rbase = atomicAdd(&out.counters[0], nrec);
-    if (rbase + nrec > out.rec_cap) {
-      atomicOr(&out.counters[1], kErrRecCap);
-      rbase = 0xFFFFFFFFu;
-    }
     out.rd_off[read] = rbase == 0xFFFFFFFFu ? 0 : rbase;
     out.rd_cnt[read] = rbase == 0xFFFFFFFFu ? 0 : nrec;
     out.rd_onmers[read] = onmers;
     out.rd_filt[2 * read] = filt0;
     out.rd_filt[2 * read + 1] = filt1;
   }
-  rbase = __shfl(rbase, 0);
   uint32_t run = 0;
   for (uint32_t t0 = 0; t0 < n2; t0 += 64) {
     uint32_t t = t0 + lane;
@@ -909,8 +924,14 @@ __global__ __launch_bounds__(kWave) void kr_probe_kernel_t(DevIndex ix, DevParam
   ws.err = 0;
   ws.read = 0;
   ws.base0 = 0;
+  ws.rec_next = 0;
+  ws.rec_end = 0;
+  ws.n_l2 = 0;
+  ws.n_rec = 0;
   ProbeList pl{s_bkt, s_q, s_tag};
   for (uint32_t r = blockIdx.x; r < in.nreads; r += gridDim.x) process_read<LOG_G, SL, TAP>(ix, P, in, out, r, A, ws, pl);
+  if (ws.n_l2 && lane_id() == 0) atomicAdd(&out.counters[2], ws.n_l2);
+  if (ws.n_rec && lane_id() == 0) atomicAdd(&out.counters[4], ws.n_rec);
 }
 
 // ---------------------------------------------------------------------------
@@ -1022,6 +1043,7 @@ __global__ __launch_bounds__(256) void kr_llh_kernel(LlhConst C, DevIndex ix, Ba
   uint32_t nrec = min(out.counters[0], out.rec_cap);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += gridDim.x * blockDim.x) {
     uint32_t key = out.rec_key[i];
+    if (key == 0) continue; // hole at the end of a wave's record chunk
     uint32_t read = out.rec_read[i];
     LlhProblem p;
     load_problem(C, out.rec_hist + (uint64_t)i * (C.th + 1), out.rd_onmers[read], ix.libs[0].rho[key >> 1], p);
@@ -1532,6 +1554,7 @@ struct kr_stream {
   uint32_t max_reads = 0;
   uint64_t max_bases = 0;
   uint32_t rec_cap = 0, hit_cap = 0;
+  uint64_t rec_user_cap = 0; // the caller's max_records (rec_cap adds per-wave chunk slack)
   uint32_t nwaves = 0;
   // device
   uint8_t* d_bases = nullptr;
@@ -1619,7 +1642,9 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   // default record capacity: up to 2 * leaves per read, at most 16 per read on average
   uint64_t per_read = std::min<uint64_t>(16, std::max<uint64_t>(8, (uint64_t)ix->dix.tree_nnodes + 1));
   uint64_t rc64 = max_records ? max_records : std::max<uint64_t>(1u << 16, (uint64_t)max_reads * per_read);
-  s->rec_cap = (uint32_t)std::min<uint64_t>(rc64, 1ull << 30);
+  s->rec_user_cap = rc64;
+  // every resident wave may leave one partly used chunk behind: add that slack to the caller's bound
+  s->rec_cap = (uint32_t)std::min<uint64_t>(rc64 + (uint64_t)s->nwaves * kRecChunk, 1ull << 30);
   s->hit_cap = 1u << 22;
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
@@ -1710,6 +1735,8 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
   }
   s->in.nreads = nreads;
   HIP_TRY(hipMemsetAsync(s->out.counters, 0, 32, st));
+  HIP_TRY(hipMemsetAsync(s->out.rec_key, 0, (uint64_t)s->rec_cap * 4, st));
+  HIP_TRY(hipMemsetAsync(s->out.rec_sel, 0, (uint64_t)s->rec_cap, st));
   HIP_TRY(hipEventRecord(s->ev[1], st));
   const DevIndex& dix = s->ix->dix;
   uint32_t grid = std::min(nreads, s->nwaves);
@@ -1766,6 +1793,8 @@ int kr_batch_wait(kr_stream* s)
   s->waited = true;
   s->nrecs = std::min(s->h_counters[0], s->rec_cap);
   s->nhits = std::min<uint64_t>(s->h_counters[3], s->hit_cap);
+  if (s->h_counters[4] > s->rec_user_cap)
+    return kr::fail(KR_ERR_CAPACITY, "the batch produced more records than max_records: submit fewer reads per batch");
   return check_errflags(s->h_counters[1]);
 }
 
