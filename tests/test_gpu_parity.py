@@ -312,3 +312,34 @@ def test_index_export_import_roundtrip(capi, toy, toy_reads):
     _, a = gpu_dist(capi, dx, bases, offs)
     _, b = gpu_dist(capi, dx2, bases, offs)
     assert a.rows() == b.rows() and len(a.rows()) > 100
+
+
+def test_cli_dist_end_to_end(capi, po, toy_index_dir, toy_reads, tmp_path):
+    """BASELINE.json configs[0] plumbing: the `krepp dist` binary on an index directory and a FASTQ
+    file; stdout must be the reference's header plus the oracle's rows (input order, 5 decimals)."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "krepp_amd", "lib", "krepp")
+    fq = os.path.join(GOLDEN, "toy_reads.fq")
+    names, bases, offs = toy_reads
+    ox = po.Index(toy_index_dir)
+    for extra, p in ([], po.params(collect=4)), (["--filter"], po.params(collect=4, no_filter=0)), \
+                    (["--no-multi", "--hdist-th", "3"], po.params(collect=4, multi=0, hdist_th=3)), \
+                    (["--dist-max", "0.05"], po.params(collect=4, dist_max=0.05)):
+        r = subprocess.run([exe, "dist", "-i", toy_index_dir, "-q", fq] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.split("\n")
+        assert lines[0].startswith("# software: krepp\tversion: v0.8.3\tinvocation :") and "dist -i" in lines[0]
+        assert lines[1] == "SEQ_ID\tREFERENCE_NAME\tDIST"
+        want = ox.dist(bases, offs, names, p)["text"]
+        assert "\n".join(lines[2:]) == want, extra
+        assert "Total number of sequences queried: 308" in r.stderr
+    # gz input and -o
+    import gzip, shutil
+    gz = tmp_path / "reads.fq.gz"
+    with open(fq, "rb") as fi, gzip.open(gz, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    out = tmp_path / "out.tsv"
+    r = subprocess.run([exe, "--num-threads", "2", "dist", "-i", toy_index_dir, "-q", str(gz), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == ""
+    assert out.read_text().split("\n", 2)[2] == ox.dist(bases, offs, names, po.params(collect=4))["text"]

@@ -226,3 +226,26 @@ def test_cli_usage_errors(capi):
     assert r.returncode == 1 and "[ERROR]" in r.stderr and "krepp version: v0.8.3" in r.stderr
     r = subprocess.run([exe, "dist", "-i", "/nonexistent", "-q", "/nonexistent"], capture_output=True, text=True)
     assert r.returncode == 1 and "[ERROR]" in r.stderr
+
+
+def test_cli_index_matches_library_builder(capi, synth, tmp_path):
+    g = synth.evolve_genomes("((a:0.03,b:0.03):0.02,(c:0.05,d:0.05):0.01);", 8000, seed=4)
+    tsv = synth.write_genomes(g, str(tmp_path / "g"))
+    nwk = tmp_path / "t.nwk"
+    nwk.write_text("((a:0.03,b:0.03):0.02,(c:0.05,d:0.05):0.01);")
+    exe = os.path.join(ROOT, "krepp_amd", "lib", "krepp")
+    d1, d2 = str(tmp_path / "cli"), str(tmp_path / "lib")
+    r = subprocess.run([exe, "index", "-i", tsv, "-o", d1, "-t", str(nwk), "-k", "21", "-w", "27", "-h", "7", "--num-threads", "2"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    capi.build_index(tsv, d2, nwk=str(nwk), k=21, w=27, h=7)
+    for f in ("cmer", "inc", "crecord", "metadata", "tree", "reflist"):
+        a = open(os.path.join(d1, f + "-m4r1-frac"), "rb").read()
+        b = open(os.path.join(d2, f + "-m4r1-frac"), "rb").read()
+        assert a == b, f
+    # default -h is k-16 and -w is k+6 when -w is not given (src/krepp.cpp:579-582)
+    d3 = str(tmp_path / "def")
+    r = subprocess.run([exe, "index", "-i", tsv, "-o", d3, "-k", "23", "-m", "64", "-r", "0", "--no-frac"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    md = open(os.path.join(d3, "metadata-m64r0-no_frac"), "rb").read()
+    assert (md[0], md[1], md[2]) == (23, 29, 7)
