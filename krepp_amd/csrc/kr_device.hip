@@ -97,7 +97,8 @@ struct LlhConst {
 
 struct DevParams {
   uint32_t th, np;       // np = th + 1 planes
-  uint32_t multi, no_filter, dmax_set, pad;
+  uint32_t multi, no_filter, dmax_set;
+  uint32_t dbg; // KR_DEBUG_SKIP (timing experiments only): 1 drop hits, 2 drop expansion, 4 skip scan
   double chisq, dist_max;
 };
 
@@ -124,6 +125,7 @@ struct BatchOut {
   uint32_t* g_counts; // [nwaves][nslots2][np]
   uint32_t* g_list;   // [nwaves][nslots2]
   uint32_t nslots2;   // 2 * nleaves
+  uint32_t g_list_words; // per wave: max(nslots2, event capacity)
   uint32_t bm_words;  // ceil(nslots2 / 32)
 };
 
@@ -330,6 +332,12 @@ struct WaveState {
   uint32_t rec_next, rec_end; // wave-private range of record slots (wave-uniform)
   uint32_t n_l2;              // reads of this wave that used level 2
   uint32_t n_rec;             // records this wave emitted
+  // event mode (reads of a single segment): leaf updates are appended as 32-bit events
+  bool evmode;      // wave-uniform
+  bool ev_full;     // wave-uniform: the event buffer overflowed
+  uint32_t nev;     // events buffered (wave-uniform)
+  uint32_t ev_cap;  // power of two
+  lds_u32* ev;      // aliases the level-1 planes + counts region
 };
 
 // SL (single library, m <= 64) is a compile-time property of the launched kernel: the library
@@ -341,11 +349,20 @@ __device__ __forceinline__ DevLib get_lib(const DevIndex& ix, uint32_t lib)
   return ix.libs[lib];
 }
 
-// Minfo::update_match (src/query.hpp:153-176) as an idempotent OR: bit `pos` of plane `hd`.
-__device__ __forceinline__ void accumulate(const DevIndex& ix, const Acc& A, WaveState& ws, uint32_t se, uint32_t tag)
+// A leaf update as one 32-bit event, ordered so that an ascending sort groups by (leaf, strand),
+// then position, then Hamming distance:  rank << 13 | strand << 12 | pos << 5 | hd.
+__device__ __forceinline__ uint32_t make_event(uint32_t rank, uint32_t tag)
 {
-  const uint32_t key = (se << 1) | tag_strand(tag);
-  const uint32_t hd = tag_hd(tag), pos = tag_pos(tag);
+  return (rank << 13) | (tag_strand(tag) << 12) | (tag_pos(tag) << 5) | tag_hd(tag);
+}
+
+// Minfo::update_match (src/query.hpp:153-176) as an idempotent OR: bit `pos` of plane `hd`.
+// Keys are (leaf rank + 1) << 1 | strand; level 2 is indexed by slot2 = 2 * rank + strand.
+__device__ __forceinline__ void accumulate_planes(const Acc& A, WaveState& ws, uint32_t ev)
+{
+  const uint32_t rs = ev >> 12; // rank << 1 | strand
+  const uint32_t key = rs + 2u;
+  const uint32_t hd = ev & 31u, pos = (ev >> 5) & 127u;
   uint32_t s = (hash_key(key) >> 8) & (kLdsSlots - 1);
 #pragma unroll 1
   for (int i = 0; i < kLdsProbeMax; ++i) {
@@ -361,25 +378,36 @@ __device__ __forceinline__ void accumulate(const DevIndex& ix, const Acc& A, Wav
     s = (s + 1) & (kLdsSlots - 1);
   }
   // level 2
-  const uint32_t slot2 = ((ix.node_info[se] >> 2) << 1) | tag_strand(tag);
-  lds_or(&A.bitmap[slot2 >> 5], 1u << (slot2 & 31));
-  __hip_atomic_fetch_or(&A.g_planes[((uint64_t)slot2 * A.np + hd) * kPlaneWords + (pos >> 5)], 1u << (pos & 31),
+  lds_or(&A.bitmap[rs >> 5], 1u << (rs & 31));
+  __hip_atomic_fetch_or(&A.g_planes[((uint64_t)rs * A.np + hd) * kPlaneWords + (pos >> 5)], 1u << (pos & 31),
                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   ws.l2 = true;
 }
 
-// Colour ids in HBM carry their class in the top two bits (set once at upload, see
-// kr_tag_colours): 0 = drop (empty set / null tree node), 1 = tree leaf, 2 = expand through
-// se_to_pse.  This replaces Tree::check_node + get_node + check_leaf (src/query.cpp:371-381)
-// and a dependent load per colour.
-constexpr uint32_t kColMask = 0x3FFFFFFFu;
-__device__ __forceinline__ bool colour_needs_expansion(const DevIndex& ix, const Acc& A, WaveState& ws, uint32_t tse,
-                                                       uint32_t tag)
+// One leaf update per lane (f = this lane has one): event append, or plane OR after fallback.
+__device__ __forceinline__ void add_leaf_events(const Acc& A, WaveState& ws, bool f, uint32_t ev)
 {
-  const uint32_t cls = tse >> 30;
-  if (cls == 1u) accumulate(ix, A, ws, tse & kColMask, tag);
-  return cls == 2u;
+  const uint64_t m = __ballot(f);
+  if (m == 0) return;
+  if (ws.evmode) {
+    const uint32_t c = __popcll(m);
+    if (ws.nev + c <= ws.ev_cap) {
+      if (f) ws.ev[ws.nev + __popcll(m & ((1ull << lane_id()) - 1ull))] = ev;
+      ws.nev += c;
+    } else {
+      ws.ev_full = true; // the read is redone with the plane tables (rare)
+    }
+    return;
+  }
+  if (f) accumulate_planes(A, ws, ev);
 }
+
+// Colour ids in HBM carry their class in the top two bits (set once at upload, see
+// kr_tag_colours): 0 = drop (empty set / null tree node), 1 = tree leaf (low bits = leaf RANK, the
+// index among leaves in colour-id order), 2 = expand through se_to_pse (low bits = colour id).
+// This replaces Tree::check_node + get_node + check_leaf (src/query.cpp:371-381) and a dependent
+// load per colour.
+constexpr uint32_t kColMask = 0x3FFFFFFFu;
 
 // Colour expansion (the BFS of src/query.cpp:369-387, order-free here): drain the work stack.
 template <bool SL, bool TAP>
@@ -406,6 +434,7 @@ __device__ __forceinline__ void expand_all(const DevIndex& ix, const BatchOut& o
     uint32_t se = item.x, tag = item.y;
     uint32_t c0 = 0, c1 = 0;
     bool p0 = false, p1 = false;
+    bool f0 = false, f1 = false, f2 = false; // leaf updates found by this lane: the item, child 0, child 1
     if (have) {
       DevLib L = get_lib<SL>(ix, tag_lib(tag));
       if (tag & kItemUnresolved) { // fetch the colour of a fresh hit
@@ -421,7 +450,7 @@ __device__ __forceinline__ void expand_all(const DevIndex& ix, const BatchOut& o
             h.lib = tag_lib(tag);
             h.cmer_index = idx;
             h.hd = tag_hd(tag);
-            h.se = se & kColMask;
+            h.se = (se >> 30) == 1u ? ix.leaf_se[se & kColMask] : (se & kColMask);
             out.hits[hix] = h;
           } else {
             atomicOr(&out.counters[1], kErrHitCap);
@@ -429,14 +458,18 @@ __device__ __forceinline__ void expand_all(const DevIndex& ix, const BatchOut& o
         }
         tag &= 0x1FFFFu;
       }
-      if (colour_needs_expansion(ix, A, ws, se, tag)) {
+      f0 = (se >> 30) == 1u;
+      if ((se >> 30) == 2u) {
         uint2 pr = L.pse[se & kColMask];
         c0 = pr.x;
         c1 = pr.y;
-        p0 = colour_needs_expansion(ix, A, ws, c0, tag);
-        p1 = colour_needs_expansion(ix, A, ws, c1, tag);
+        f1 = (c0 >> 30) == 1u, p0 = (c0 >> 30) == 2u;
+        f2 = (c1 >> 30) == 1u, p1 = (c1 >> 30) == 2u;
       }
     }
+    add_leaf_events(A, ws, f0, make_event(se & kColMask, tag));
+    add_leaf_events(A, ws, f1, make_event(c0 & kColMask, tag));
+    add_leaf_events(A, ws, f2, make_event(c1 & kColMask, tag));
     uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
     if (p0) ws.stack[ws.top + __popcll(m0 & lt)] = (uint64_t)c0 | ((uint64_t)tag << 32);
     ws.top += __popcll(m0);
@@ -536,11 +569,12 @@ __device__ __forceinline__ void scan_issue(const DevIndex& ix, const ProbeList& 
 template <bool SL, bool TAP>
 __device__ __forceinline__ void push_hits(const DevIndex& ix, const BatchOut& out, const Acc& A, WaveState& ws, uint32_t tg,
                                           uint64_t eA, uint64_t eB, uint32_t mA, uint32_t hA, uint32_t mB, uint32_t hB,
-                                          uint32_t& filt0, uint32_t& filt1)
+                                          uint32_t& filt0, uint32_t& filt1, uint32_t P_dbg)
 {
   const uint32_t lane = lane_id();
   const uint64_t lt = (1ull << lane) - 1ull;
   uint32_t pend = mA | (mB << 4);
+  if (P_dbg & 1u) pend = 0;
   while (__ballot(pend != 0) != 0) {
     if (ws.top > (uint32_t)(kStackCap - 64)) expand_all<SL, TAP>(ix, out, A, ws);
     const bool has = pend != 0;
@@ -582,7 +616,7 @@ __device__ __forceinline__ void scan_list(const DevIndex& ix, const DevParams& P
       const uint64_t eB = cur.eA + 4ull * G;
       if (sub < cur.nch) chunk_hits(cur.vA, cur.eA, cur.st, cur.ln, cur.q, P.th, mA, hA);
       if (sub + G < cur.nch) chunk_hits(cur.vB, eB, cur.st, cur.ln, cur.q, P.th, mB, hB);
-      push_hits<SL, TAP>(ix, out, A, ws, cur.tg, cur.eA, eB, mA, hA, mB, hB, filt0, filt1);
+      push_hits<SL, TAP>(ix, out, A, ws, cur.tg, cur.eA, eB, mA, hA, mB, hB, filt0, filt1, P.dbg);
     }
     // ---- buckets longer than 2*G chunks: the rest, two chunks per lane at a time
     if (__ballot(cur.nch > 2u * G) != 0) {
@@ -596,7 +630,7 @@ __device__ __forceinline__ void scan_list(const DevIndex& ix, const DevParams& P
         uint32_t mA = 0, hA = 0, mB = 0, hB = 0;
         if (onA) chunk_hits(vA, eA, cur.st, cur.ln, cur.q, P.th, mA, hA);
         if (onB) chunk_hits(vB, eB, cur.st, cur.ln, cur.q, P.th, mB, hB);
-        push_hits<SL, TAP>(ix, out, A, ws, cur.tg, eA, eB, mA, hA, mB, hB, filt0, filt1);
+        push_hits<SL, TAP>(ix, out, A, ws, cur.tg, eA, eB, mA, hA, mB, hB, filt0, filt1, P.dbg);
       }
     }
     cur = nxt;
@@ -699,12 +733,160 @@ __device__ __forceinline__ uint32_t alloc_records(const BatchOut& out, WaveState
 }
 
 // ---------------------------------------------------------------------------
+// Event mode epilogue: sort the events, keep the first event of every (leaf, strand, pos) group
+// (= the smallest hd at that position: the rule of Minfo::update_match, src/query.hpp:153-176),
+// histogram per (leaf, strand), apply the hdist_filt test, emit records in key order.
+// All in LDS; the histogram table lives in the (now idle) stack + probe-list regions.
+// Returns false if the read has more distinct keys than the table holds (caller falls back).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void bitonic_sort_lds(lds_u32* e, uint32_t n) // n: power of two >= 64
+{
+  const uint32_t lane = lane_id();
+  if (n == 64) { // one element per lane: sort in registers
+    uint32_t v = e[lane];
+#pragma unroll
+    for (uint32_t k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        uint32_t o = __shfl_xor(v, j);
+        bool up = (lane & k) == 0, lower = (lane & j) == 0;
+        v = (lower == up) ? min(v, o) : max(v, o);
+      }
+    }
+    e[lane] = v;
+    WAVE_SYNC();
+    return;
+  }
+  for (uint32_t k = 2; k <= n; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t t = lane; t < (n >> 1); t += 64) {
+        uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), q = i + j;
+        uint32_t a = e[i], b = e[q];
+        bool up = (i & k) == 0;
+        if ((a > b) == up) {
+          e[i] = b;
+          e[q] = a;
+        }
+      }
+      WAVE_SYNC();
+    }
+  }
+}
+
+__device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchOut& out, const Acc& A, WaveState& ws,
+                                                lds_u32* hist, uint32_t hist_words, uint32_t read, uint32_t onmers,
+                                                uint32_t filt0, uint32_t filt1)
+{
+  const uint32_t lane = lane_id();
+  const uint64_t le = (2ull << lane) - 1ull, lt = (1ull << lane) - 1ull;
+  const uint32_t nev = ws.nev;
+  const uint32_t lim0 = 2u * filt0 + 1u, lim1 = 2u * filt1 + 1u; // u32 wrap keeps "none" = max
+  lds_u32* e = ws.ev;
+  uint32_t nrec = 0, nkeys = 0, npad = 0;
+  if (nev) {
+    npad = 64;
+    while (npad < nev) npad <<= 1;
+    for (uint32_t i = nev + lane; i < npad; i += 64) e[i] = 0xFFFFFFFFu;
+    WAVE_SYNC();
+    bitonic_sort_lds(e, npad);
+    // ---- distinct (leaf, strand) keys
+    for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
+      uint32_t i = t0 + lane;
+      bool kl = i < nev && (i == 0 || (e[i] >> 12) != (e[i - 1] >> 12));
+      nkeys += __popcll(__ballot(kl));
+    }
+    const uint32_t hw = (A.np + 3u) >> 2; // four 8-bit counters per word: a segment has <= 128 positions
+    if (nkeys * hw > hist_words) return false;
+    for (uint32_t i = lane; i < nkeys * hw; i += 64) hist[i] = 0;
+    WAVE_SYNC();
+    // ---- histogram of the position leaders; key table written in place over the sorted events
+    uint32_t run = 0, carry = 0xFFFFFFFFu; // carry = last event of the previous tile (kept in a register:
+                                           // the key table is written over the events as we go)
+    for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
+      uint32_t i = t0 + lane;
+      bool valid = i < nev;
+      uint32_t v = valid ? e[i] : 0xFFFFFFFFu;
+      uint32_t pv = __shfl_up(v, 1);
+      if (lane == 0) pv = carry;
+      carry = __shfl(v, 63);
+      bool kl = valid && (i == 0 || (v >> 12) != (pv >> 12));
+      bool plead = valid && (i == 0 || (v >> 5) != (pv >> 5));
+      uint64_t km = __ballot(kl);
+      uint32_t ord = run + __popcll(km & le) - 1u; // ordinal of my key (ord <= i)
+      WAVE_SYNC();                                  // every lane holds its event before the table is written
+      if (kl) e[ord] = v >> 12;
+      if (plead)
+        __hip_atomic_fetch_add(&hist[ord * hw + ((v & 31u) >> 2)], 1u << (8u * (v & 3u)), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+      run += __popcll(km);
+      WAVE_SYNC();
+    }
+    // ---- records that pass `hdist_min <= 2*hdist_filt+1` (src/query.cpp:101-106,119)
+    for (uint32_t t0 = 0; t0 < nkeys; t0 += 64) {
+      uint32_t o = t0 + lane;
+      bool ok = false;
+      if (o < nkeys) {
+        uint32_t hmin = 0xFFFFFFFFu;
+        for (uint32_t x = 0; x < A.np; ++x)
+          if ((hist[o * hw + (x >> 2)] >> (8u * (x & 3u))) & 255u) {
+            hmin = x;
+            break;
+          }
+        ok = hmin <= ((e[o] & 1u) ? lim1 : lim0);
+      }
+      nrec += __popcll(__ballot(ok));
+    }
+  }
+  const uint32_t rbase = nrec ? alloc_records(out, ws, nrec) : 0u;
+  if (lane == 0) {
+    out.rd_off[read] = rbase == 0xFFFFFFFFu ? 0 : rbase;
+    out.rd_cnt[read] = rbase == 0xFFFFFFFFu ? 0 : nrec;
+    out.rd_onmers[read] = onmers;
+    out.rd_filt[2 * read] = filt0;
+    out.rd_filt[2 * read + 1] = filt1;
+  }
+  if (nrec && rbase != 0xFFFFFFFFu) {
+    const uint32_t hw = (A.np + 3u) >> 2;
+    uint32_t run = 0;
+    for (uint32_t t0 = 0; t0 < nkeys; t0 += 64) {
+      uint32_t o = t0 + lane;
+      bool ok = false;
+      uint32_t rs = 0;
+      if (o < nkeys) {
+        rs = e[o];
+        uint32_t hmin = 0xFFFFFFFFu;
+        for (uint32_t x = 0; x < A.np; ++x)
+          if ((hist[o * hw + (x >> 2)] >> (8u * (x & 3u))) & 255u) {
+            hmin = x;
+            break;
+          }
+        ok = hmin <= ((rs & 1u) ? lim1 : lim0);
+      }
+      uint64_t okm = __ballot(ok);
+      if (ok) {
+        uint32_t ri = rbase + run + __popcll(okm & lt);
+        out.rec_read[ri] = read;
+        out.rec_key[ri] = (ix.leaf_se[rs >> 1] << 1) | (rs & 1u);
+        for (uint32_t x = 0; x < A.np; ++x)
+          out.rec_hist[(uint64_t)ri * A.np + x] = (hist[o * hw + (x >> 2)] >> (8u * (x & 3u))) & 255u;
+      }
+      run += __popcll(okm);
+    }
+  }
+  // the event buffer aliases the plane tables: leave it zeroed
+  WAVE_SYNC();
+  for (uint32_t i = lane; i < npad; i += 64) e[i] = 0;
+  WAVE_SYNC();
+  return true;
+}
+
+// ---------------------------------------------------------------------------
 // One read.
 // ---------------------------------------------------------------------------
 template <int LOG_G, bool SL, bool TAP>
 __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams& P, const BatchIn& in,
                                              const BatchOut& out, uint32_t read, const Acc& A, WaveState& ws,
-                                             const ProbeList& pl)
+                                             const ProbeList& pl, lds_u32* hist_tbl, uint32_t hist_words)
 {
   const uint32_t lane = lane_id();
   const uint64_t lt = (1ull << lane) - 1ull;
@@ -716,10 +898,17 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   uint32_t onmers = 0;
   uint32_t filt0 = 0xFFFFFFFFu, filt1 = 0xFFFFFFFFu;
   bool l2_any = false; // wave-uniform: some key of this read lives in level 2
+  ws.read = read;
+  ws.evmode = nkm <= (uint64_t)kSegPos && !(P.dbg & 8u); // single segment: event mode
+  // A read is processed once; only if its events do not fit (buffer or histogram table) is it
+  // processed a second time with the plane tables.
+  for (;;) {
+  onmers = 0;
+  filt0 = 0xFFFFFFFFu, filt1 = 0xFFFFFFFFu;
   ws.top = 0;
   ws.l2 = false;
-  ws.read = read;
-
+  ws.nev = 0;
+  ws.ev_full = false;
   for (uint64_t base0 = 0; base0 < nkm; base0 += kSegPos) {
     const uint32_t npos_seg = (uint32_t)min((uint64_t)kSegPos, nkm - base0);
     ws.base0 = (uint32_t)base0;
@@ -753,11 +942,13 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
         pl.tag[i] = (64u * pp + lane) | (1u << 7) | (cur.lib1 << 8);
       }
       WAVE_SYNC();
-      scan_list<LOG_G, SL, TAP>(ix, P, out, A, ws, pl, nact, filt0, filt1);
+      if (!(P.dbg & 4u)) scan_list<LOG_G, SL, TAP>(ix, P, out, A, ws, pl, nact, filt0, filt1);
       WAVE_SYNC();
       cur = nxt;
     }
+    if (P.dbg & 2u) ws.top = 0;
     expand_all<SL, TAP>(ix, out, A, ws);
+    if (ws.evmode) break; // single segment, nothing to fold: finalize_events does the rest
     // ---- fold this segment's planes into running counts (positions of different
     //      segments are distinct, so histograms add)
     WAVE_SYNC();
@@ -778,13 +969,21 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   }
   if (ws.err && lane == 0) atomicOr(&out.counters[1], ws.err);
   ws.err = 0;
+  if (!ws.evmode) break;
+  if (!ws.ev_full && finalize_events(ix, out, A, ws, hist_tbl, hist_words, read, onmers, filt0, filt1)) return;
+  // does not fit: zero the aliased region and redo the read with the plane tables
+  WAVE_SYNC();
+  for (uint32_t i = lane; i < (uint32_t)kLdsSlots * A.np * (kPlaneWords + 1); i += 64) A.planes[i] = 0;
+  WAVE_SYNC();
+  ws.evmode = false;
+  } // redo loop
   // records that pass `hdist_min <= 2*hdist_filt+1` (src/query.cpp:101-106,119), ordered by key so
   // that the two strands of a leaf are adjacent
   const uint32_t lim0 = 2u * filt0 + 1u, lim1 = 2u * filt1 + 1u; // u32 wrap keeps "none" = max
 
   if (!l2_any) {
     // ---- level 1 only: lane t owns slot t
-    const uint32_t key = A.keys[lane];
+    const uint32_t key = A.keys[lane]; // (rank + 1) << 1 | strand: ascending key == ascending colour id
     const bool ok = key && hmin_l1(A, lane) <= ((key & 1u) ? lim1 : lim0);
     uint64_t okm = __ballot(ok);
     const uint32_t nrec = __popcll(okm);
@@ -806,7 +1005,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
     if (ok && rbase != 0xFFFFFFFFu) {
       uint32_t ri = rbase + rank;
       out.rec_read[ri] = read;
-      out.rec_key[ri] = key;
+      out.rec_key[ri] = (ix.leaf_se[(key >> 1) - 1u] << 1) | (key & 1u);
       for (uint32_t x = 0; x < A.np; ++x) out.rec_hist[(uint64_t)ri * A.np + x] = A.counts[lane * A.np + x];
     }
     if (key) { // leave the slot empty for the next read
@@ -821,8 +1020,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   {
     const uint32_t key = A.keys[lane];
     if (key) {
-      uint32_t info = ix.node_info[key >> 1];
-      uint32_t slot2 = ((info >> 2) << 1) | (key & 1u);
+      uint32_t slot2 = key - 2u;
       for (uint32_t x = 0; x < A.np; ++x) {
         uint32_t c = A.counts[lane * A.np + x];
         if (c) {
@@ -882,7 +1080,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
 }
 
 template <int LOG_G, bool SL, bool TAP>
-__global__ __launch_bounds__(kWave) void kr_probe_kernel_t(DevIndex ix, DevParams P, BatchIn in, BatchOut out)
+__global__ __launch_bounds__(kWave, 4) void kr_probe_kernel_t(DevIndex ix, DevParams P, BatchIn in, BatchOut out)
 {
   // One carve of dynamic LDS (base is 16-byte aligned: no static __shared__ in front):
   //   stack | probe list | level-1 table (keys, planes, counts) | level-2 bitmap
@@ -905,7 +1103,7 @@ __global__ __launch_bounds__(kWave) void kr_probe_kernel_t(DevIndex ix, DevParam
   const uint64_t w = blockIdx.x;
   A.g_planes = out.g_planes + w * (uint64_t)out.nslots2 * P.np * kPlaneWords;
   A.g_counts = out.g_counts + w * (uint64_t)out.nslots2 * P.np;
-  A.g_list = out.g_list + w * (uint64_t)out.nslots2;
+  A.g_list = out.g_list + w * (uint64_t)out.g_list_words;
   { // tables start empty; every read leaves them empty again
     const uint32_t lane = lane_id();
     A.keys[lane] = 0;
@@ -928,8 +1126,13 @@ __global__ __launch_bounds__(kWave) void kr_probe_kernel_t(DevIndex ix, DevParam
   ws.rec_end = 0;
   ws.n_l2 = 0;
   ws.n_rec = 0;
+  ws.evmode = false;
+  ws.nev = 0;
+  ws.ev = A.planes; // planes + counts are contiguous: kLdsSlots * np * 5 words
+  ws.ev_cap = 64;
+  while (ws.ev_cap * 2 <= (uint32_t)kLdsSlots * P.np * (kPlaneWords + 1)) ws.ev_cap <<= 1;
   ProbeList pl{s_bkt, s_q, s_tag};
-  for (uint32_t r = blockIdx.x; r < in.nreads; r += gridDim.x) process_read<LOG_G, SL, TAP>(ix, P, in, out, r, A, ws, pl);
+  for (uint32_t r = blockIdx.x; r < in.nreads; r += gridDim.x) process_read<LOG_G, SL, TAP>(ix, P, in, out, r, A, ws, pl, (lds_u32*)s_base, (kStackCap * 8 + kListCap * 16) / 4);
   if (ws.n_l2 && lane_id() == 0) atomicAdd(&out.counters[2], ws.n_l2);
   if (ws.n_rec && lane_id() == 0) atomicAdd(&out.counters[4], ws.n_rec);
 }
@@ -1172,7 +1375,8 @@ __device__ __forceinline__ uint32_t tag_colour(uint32_t se, const uint32_t* node
 {
   if (se == 0 || se >= nsubsets || se > kColMask) return 0; // empty set, or an id the crecord does not define
   if (se <= tree_nnodes) {
-    uint32_t kd = node_info[se] & 3u;
+    uint32_t info = node_info[se], kd = info & 3u;
+    if (kd == 1u) return (info >> 2) | (1u << 30); // leaf: its rank
     return kd ? (se | (kd << 30)) : 0u;
   }
   return se | (2u << 30);
@@ -1630,6 +1834,7 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   s->dp.th = p->hdist_th, s->dp.np = p->hdist_th + 1;
   s->dp.multi = p->multi, s->dp.no_filter = p->no_filter;
   s->dp.dmax_set = std::isnan(p->dist_max) ? 0 : 1;
+  s->dp.dbg = getenv("KR_DEBUG_SKIP") ? (uint32_t)atoi(getenv("KR_DEBUG_SKIP")) : 0u;
   s->dp.chisq = p->chisq, s->dp.dist_max = p->dist_max;
   s->llh = make_llh_const(ix->dix.k, ix->dix.h, p->hdist_th);
   s->max_reads = max_reads, s->max_bases = max_bases;
@@ -1674,10 +1879,12 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   o.rec_cap = s->rec_cap;
   o.hit_cap = s->hit_cap;
   o.nslots2 = nslots2;
+  const uint32_t g_list_words = std::max<uint32_t>(nslots2, (uint32_t)kLdsSlots * np * (kPlaneWords + 1));
+  o.g_list_words = g_list_words;
   o.bm_words = bm_words;
   SA(o.g_planes, (uint64_t)s->nwaves * nslots2 * np * kPlaneWords);
   SA(o.g_counts, (uint64_t)s->nwaves * nslots2 * np);
-  SA(o.g_list, (uint64_t)s->nwaves * nslots2);
+  SA(o.g_list, (uint64_t)s->nwaves * g_list_words);
   HIP_TRY(hipMemset(o.g_planes, 0, (uint64_t)s->nwaves * nslots2 * np * kPlaneWords * 4));
   HIP_TRY(hipMemset(o.g_counts, 0, (uint64_t)s->nwaves * nslots2 * np * 4));
   HA(s->h_bases, max_bases + 256);
