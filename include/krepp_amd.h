@@ -256,9 +256,29 @@ typedef struct kr_build_params {
   uint32_t num_threads;
   uint32_t seed;
   const uint8_t* ppos;          /* optional explicit LSH positions [h] (descending)    */
+  uint32_t gpu_minimizers;      /* 1: leaf stage (window minimizers) on the GPU `device`; */
+  int32_t device;               /*    identical output, checked by tests/test_minimizers.py */
 } kr_build_params;
 KR_API int kr_build_index(const char* input_tsv, const char* nwk_path /*may be NULL*/, const char* out_dir,
                           const kr_build_params*);
+
+/* The leaf stage of the build on its own: RSeq::extract_mers (src/rqseq.cpp:51-144) + the
+ * sort/unique of DynHT::fill_table (src/table.cpp:247-260) for ONE genome held in memory
+ * (contigs concatenated, offsets[ncontigs+1]).  keys = (row << 32) | enc32, sorted, unique;
+ * n1/n2 = sums over contigs of the HyperLogLog(12) estimates of distinct k-mers / distinct
+ * window minimizers (rho = n2 / n1, src/rqseq.hpp:79).  `ppos` must be given.
+ * _cpu is the builder's own code path; _device computes the window minima on the GPU
+ * (wave ballots for the 2-bit strings, LDS window minimum) and must return identical results. */
+typedef struct kr_minimizer_result {
+  uint64_t* keys;
+  uint64_t nkeys;
+  double n1, n2;
+} kr_minimizer_result;
+KR_API int kr_minimizers_cpu(const kr_build_params*, const uint8_t* bases, const uint64_t* offsets, uint32_t ncontigs,
+                             kr_minimizer_result* out);
+KR_API int kr_minimizers_device(int device, const kr_build_params*, const uint8_t* bases, const uint64_t* offsets,
+                                uint32_t ncontigs, kr_minimizer_result* out);
+KR_API void kr_minimizers_free(kr_minimizer_result*);
 
 KR_API const char* kr_last_error(void);
 KR_API const char* kr_version(void);

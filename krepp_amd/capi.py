@@ -70,9 +70,14 @@ class KrFastxBatch(C.Structure):
                 ("nreads", C.c_uint32), ("more", C.c_uint32)]
 
 
+class KrMinimizerResult(C.Structure):
+    _fields_ = [("keys", u64p), ("nkeys", C.c_uint64), ("n1", C.c_double), ("n2", C.c_double)]
+
+
 class KrBuildParams(C.Structure):
     _fields_ = [("k", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32), ("m", C.c_uint32), ("r", C.c_uint32),
-                ("frac", C.c_uint32), ("num_threads", C.c_uint32), ("seed", C.c_uint32), ("ppos", u8p)]
+                ("frac", C.c_uint32), ("num_threads", C.c_uint32), ("seed", C.c_uint32), ("ppos", u8p),
+                ("gpu_minimizers", C.c_uint32), ("device", C.c_int32)]
 
 
 # every symbol include/krepp_amd.h declares (tests check that the library exports them all)
@@ -84,7 +89,7 @@ EXPORTS = [
     "kr_batch_collect", "kr_batch_collect_device", "kr_batch_hits", "kr_batch_readtaps",
     "kr_debug_front_end", "kr_debug_brent", "kr_batch_timing",
     "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_format_dist", "kr_free",
-    "kr_build_index", "kr_last_error", "kr_version",
+    "kr_build_index", "kr_minimizers_cpu", "kr_minimizers_device", "kr_minimizers_free", "kr_last_error", "kr_version",
 ]
 
 _lib = None
@@ -147,6 +152,10 @@ def load():
     lib.kr_free.argtypes = [vp]
     lib.kr_free.restype = None
     lib.kr_build_index.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(KrBuildParams)]
+    lib.kr_minimizers_cpu.argtypes = [C.POINTER(KrBuildParams), vp, vp, C.c_uint32, C.POINTER(KrMinimizerResult)]
+    lib.kr_minimizers_device.argtypes = [C.c_int, C.POINTER(KrBuildParams), vp, vp, C.c_uint32, C.POINTER(KrMinimizerResult)]
+    lib.kr_minimizers_free.argtypes = [C.POINTER(KrMinimizerResult)]
+    lib.kr_minimizers_free.restype = None
     _lib = lib
     return lib
 
@@ -435,13 +444,35 @@ def read_fastx(path, min_bases=76800):
     return names, bases, offsets
 
 
-def build_index(input_tsv, out_dir, nwk=None, k=29, w=35, h=13, m=4, r=1, frac=True, num_threads=1, seed=0, ppos=None):
+def build_index(input_tsv, out_dir, nwk=None, k=29, w=35, h=13, m=4, r=1, frac=True, num_threads=1, seed=0, ppos=None,
+                gpu_minimizers=False, device=0):
     """`krepp index` on the CPU (reference: src/krepp.cpp:131-303)."""
     lib = load()
-    p = KrBuildParams(k=k, w=w, h=h, m=m, r=r, frac=int(frac), num_threads=num_threads, seed=seed, ppos=None)
+    p = KrBuildParams(k=k, w=w, h=h, m=m, r=r, frac=int(frac), num_threads=num_threads, seed=seed, ppos=None,
+                      gpu_minimizers=int(gpu_minimizers), device=device)
     keep = None
     if ppos is not None:
         keep = (C.c_uint8 * len(ppos))(*ppos)
         p.ppos = C.cast(keep, u8p)
     check(lib.kr_build_index(os.fsencode(str(input_tsv)), os.fsencode(str(nwk)) if nwk else None,
                              os.fsencode(str(out_dir)), C.byref(p)))
+
+
+def minimizers(bases, offsets, k, w, h, ppos, m=4, r=1, frac=True, device=None):
+    """(keys, n1, n2) of one genome: kr_minimizers_cpu (device=None) or kr_minimizers_device."""
+    lib = load()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    keep = (C.c_uint8 * len(ppos))(*ppos)
+    p = KrBuildParams(k=k, w=w, h=h, m=m, r=r, frac=int(frac), num_threads=1, seed=0, ppos=C.cast(keep, u8p),
+                      gpu_minimizers=0, device=0)
+    res = KrMinimizerResult()
+    if device is None:
+        check(lib.kr_minimizers_cpu(C.byref(p), bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, C.byref(res)))
+    else:
+        check(lib.kr_minimizers_device(int(device), C.byref(p), bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
+                                       C.byref(res)))
+    keys = _np(res.keys, res.nkeys, np.uint64)
+    out = (keys, res.n1, res.n2)
+    lib.kr_minimizers_free(C.byref(res))
+    return out

@@ -47,15 +47,9 @@ inline unsigned code_of(unsigned char c)
   }
 }
 
-inline uint64_t fmix64(uint64_t v)
-{ // xur64_hash, src/common.hpp:147-155
-  v ^= v >> 33;
-  v *= 0xff51afd7ed558ccdull;
-  v ^= v >> 33;
-  v *= 0xc4ceb9fe1a85ec53ull;
-  v ^= v >> 33;
-  return v;
-}
+} // namespace
+
+namespace kr {
 
 // HyperLogLog with b=12 as the reference instantiates it (src/rqseq.cpp:63-64,
 // src/hyperloglog.hpp:98-135): index = top b bits of the 32-bit hash, rank =
@@ -74,63 +68,59 @@ struct Hll {
     uint8_t rank = (uint8_t)(std::min(32 - b, lz) + 1);
     if (rank > reg[ix]) reg[ix] = rank;
   }
-  double estimate() const
-  {
-    const double mreg = (double)reg.size();
-    const double alpha_mm = (0.7213 / (1.0 + 1.079 / mreg)) * mreg * mreg;
-    double sum = 0.0;
-    uint32_t zeros = 0;
-    for (uint8_t v : reg) {
-      sum += 1.0 / (double)(1u << v);
-      zeros += v == 0;
-    }
-    double est = alpha_mm / sum;
-    if (est <= 2.5 * mreg) {
-      if (zeros) est = mreg * std::log(mreg / zeros);
-    } else if (est > (1.0 / 30.0) * 4294967296.0) {
-      est = -4294967296.0 * std::log(1.0 - est / 4294967296.0);
-    }
-    return est;
-  }
 };
 
-struct LshPositions {
-  uint32_t k, h;
-  std::vector<uint8_t> ppos, npos; // descending / ascending
-  std::vector<uint8_t> pasc;       // ppos ascending
-  // closed form of LSHF::compute_hash and drop_ppos_lr
-  uint32_t rix(uint64_t bp) const
-  {
-    uint32_t v = 0;
-    for (uint32_t j = 0; j < h; ++j) v |= (uint32_t)((bp >> (2 * pasc[j])) & 3u) << (2 * j);
-    return v;
+double hll12_estimate(const uint8_t* reg)
+{
+  const double mreg = 4096.0;
+  const double alpha_mm = (0.7213 / (1.0 + 1.079 / mreg)) * mreg * mreg;
+  double sum = 0.0;
+  uint32_t zeros = 0;
+  for (int i = 0; i < 4096; ++i) {
+    sum += 1.0 / (double)(1u << reg[i]);
+    zeros += reg[i] == 0;
   }
-  uint32_t enc32(uint64_t bp) const
-  {
-    uint32_t v = 0;
-    for (uint32_t j = 0; j < k - h; ++j) {
-      uint32_t c = (uint32_t)((bp >> (2 * npos[j])) & 3u);
-      v |= (c & 1u) << j;
-      v |= (c >> 1) << (16 + j);
-    }
-    return v;
+  double est = alpha_mm / sum;
+  if (est <= 2.5 * mreg) {
+    if (zeros) est = mreg * std::log(mreg / zeros);
+  } else if (est > (1.0 / 30.0) * 4294967296.0) {
+    est = -4294967296.0 * std::log(1.0 - est / 4294967296.0);
   }
-};
+  return est;
+}
 
-struct Genome {
-  std::string name, path;
-  std::vector<uint64_t> keys; // (row << 32) | enc32, sorted unique
-  double n1 = 0, n2 = 0;      // HLL sums over contigs
-  bool present = false;
-};
+uint32_t LshPositions::rix(uint64_t bp) const
+{
+  uint32_t v = 0;
+  for (uint32_t j = 0; j < h; ++j) v |= (uint32_t)((bp >> (2 * pasc[j])) & 3u) << (2 * j);
+  return v;
+}
+uint32_t LshPositions::enc32(uint64_t bp) const
+{
+  uint32_t v = 0;
+  for (uint32_t j = 0; j < k - h; ++j) {
+    uint32_t c = (uint32_t)((bp >> (2 * npos[j])) & 3u);
+    v |= (c & 1u) << j;
+    v |= (c >> 1) << (16 + j);
+  }
+  return v;
+}
 
-struct BuildCfg {
-  uint32_t k, w, h, m, r;
-  bool frac;
-};
+bool make_positions(uint32_t k, uint32_t h, const uint8_t* ppos, LshPositions& lsh)
+{
+  lsh.k = k, lsh.h = h;
+  lsh.ppos.assign(ppos, ppos + h);
+  std::sort(lsh.ppos.begin(), lsh.ppos.end(), std::greater<uint8_t>());
+  lsh.pasc.assign(lsh.ppos.rbegin(), lsh.ppos.rend());
+  lsh.npos.clear();
+  for (uint8_t p = 0; p < k; ++p)
+    if (!std::count(lsh.ppos.begin(), lsh.ppos.end(), p)) lsh.npos.push_back(p);
+  return lsh.pasc.size() == h && lsh.pasc.back() < k && lsh.npos.size() == k - h;
+}
 
 // RSeq::extract_mers (src/rqseq.cpp:51-144) for one contig, sdust off.
-void extract_contig(const uint8_t* seq, uint64_t len, const BuildCfg& c, const LshPositions& lsh, Genome& g)
+void extract_contig_cpu(const uint8_t* seq, uint64_t len, const BuildCfg& c, const LshPositions& lsh,
+                        std::vector<uint64_t>& keys, double& n1, double& n2)
 {
   uint32_t k = c.k, w = c.w;
   uint32_t ldiff = w > k ? w - k + 1 : 1;
@@ -165,16 +155,66 @@ void extract_contig(const uint8_t* seq, uint64_t len, const BuildCfg& c, const L
       if (win[q].z < win[best].z) best = q;
     const Slot& mn = win[best];
     c2.add((uint32_t)mn.z);
-    uint32_t rix = lsh.rix(mn.x);
-    uint32_t res = rix % c.m;
-    if (c.frac ? res <= c.r : res == c.r) {
-      uint32_t row = c.frac ? rix / c.m * (c.r + 1) + res : rix / c.m;
-      g.keys.push_back(((uint64_t)row << 32) | lsh.enc32(mn.x));
-    }
+    int64_t row = build_row(lsh.rix(mn.x), c);
+    if (row >= 0) keys.push_back(((uint64_t)row << 32) | lsh.enc32(mn.x));
   }
-  g.n1 += c1.estimate();
-  g.n2 += c2.estimate();
+  n1 += hll12_estimate(c1.reg.data());
+  n2 += hll12_estimate(c2.reg.data());
 }
+
+bool contig_end_special(const uint8_t* seq, uint64_t len, const BuildCfg& c, uint64_t& x, uint64_t& z)
+{
+  const uint32_t k = c.k, w = std::max(c.w, c.k), ldiff = w - k + 1;
+  // length of the final run of valid bases
+  uint64_t l = 0;
+  while (l < len && code_of(seq[len - 1 - l]) < 4) ++l;
+  if (l < k || l >= w) return false; // no k-mer at the end, or the regular window rule applies
+  // the ring buffer holds the last `ldiff` k-mers computed anywhere in the contig (it is never
+  // reset), and zeros where fewer than ldiff have been computed
+  const uint64_t mask_bp = ~0ull >> ((32 - k) * 2);
+  std::vector<uint64_t> xs; // most recent first
+  uint64_t i = len;
+  while (i > 0 && xs.size() < ldiff) {
+    // k-mer ending at base i-1 is valid iff the k bases [i-k, i) are valid
+    if (i >= k) {
+      bool ok = true;
+      uint64_t bp = 0;
+      for (uint64_t q = i - k; q < i; ++q) {
+        unsigned cd = code_of(seq[q]);
+        if (cd >= 4) {
+          ok = false;
+          break;
+        }
+        bp = (bp << 2) + cd;
+      }
+      if (ok) xs.push_back(bp & mask_bp);
+    }
+    --i;
+  }
+  bool have_zero = xs.size() < ldiff;
+  x = 0, z = 0;
+  bool first = true;
+  for (uint64_t v : xs) {
+    uint64_t hz = fmix64(v);
+    if (first || hz < z) x = v, z = hz, first = false;
+  }
+  if (have_zero && (first || 0 < z)) x = 0, z = 0; // a never-written slot {0,0,0} wins unless some hash is 0
+  return true;
+}
+
+} // namespace kr
+
+namespace {
+using kr::BuildCfg;
+using kr::LshPositions;
+using kr::fmix64;
+
+struct Genome {
+  std::string name, path;
+  std::vector<uint64_t> keys; // (row << 32) | enc32, sorted unique
+  double n1 = 0, n2 = 0;      // HLL sums over contigs
+  bool present = false;
+};
 
 // Record / Subset (src/record.cpp:5-107): colour sets identified by the wrapping sum
 // of their leaves' 64-bit name hashes.
@@ -391,14 +431,42 @@ extern "C" int kr_build_index(const char* input_tsv, const char* nwk_path, const
       continue;
     }
     kr_fastx_batch b;
+    std::vector<uint8_t> all_bases; // gpu_minimizers: the whole genome goes to the device at once
+    std::vector<uint64_t> all_offs{0};
     do {
       kr_fastx_next(fx, 1, &b); // one record at a time keeps contigs separate
       for (uint32_t q = 0; q < b.nreads; ++q) {
         uint64_t len = b.offsets[q + 1] - b.offsets[q];
-        if (len >= c.w) extract_contig(b.bases + b.offsets[q], len, c, lsh, g); // RSeq::set_curr_seq: len >= w
+        if (bp->gpu_minimizers) {
+          all_bases.insert(all_bases.end(), b.bases + b.offsets[q], b.bases + b.offsets[q + 1]);
+          all_offs.push_back(all_bases.size());
+        } else if (len >= c.w) {
+          kr::extract_contig_cpu(b.bases + b.offsets[q], len, c, lsh, g.keys, g.n1, g.n2); // RSeq::set_curr_seq: len >= w
+        }
       }
     } while (b.more);
     kr_fastx_close(fx);
+    if (bp->gpu_minimizers) {
+      kr_build_params bq = *bp;
+      bq.ppos = lsh.ppos.data();
+      kr_minimizer_result mr;
+      memset(&mr, 0, sizeof(mr));
+      int mrc;
+#if defined(_OPENMP)
+#pragma omp critical(kr_gpu_minimizers)
+#endif
+      mrc = kr_minimizers_device(bp->device, &bq, all_bases.data(), all_offs.data(), (uint32_t)all_offs.size() - 1, &mr);
+      if (mrc != KR_OK) {
+#if defined(_OPENMP)
+#pragma omp critical
+#endif
+        if (first_err.empty()) first_err = std::string("GPU minimizers: ") + kr_last_error();
+        continue;
+      }
+      g.keys.assign(mr.keys, mr.keys + mr.nkeys);
+      g.n1 = mr.n1, g.n2 = mr.n2;
+      kr_minimizers_free(&mr);
+    }
     std::sort(g.keys.begin(), g.keys.end());
     g.keys.erase(std::unique(g.keys.begin(), g.keys.end()), g.keys.end());
     g.present = true;
@@ -513,4 +581,57 @@ extern "C" int kr_build_index(const char* input_tsv, const char* nwk_path, const
   }
   if (!ok) return kr::fail(KR_ERR_IO, std::string("failed to write index files under ") + out_dir);
   return KR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Leaf stage on its own (CPU): the reference path for kr_minimizers_device.
+// ---------------------------------------------------------------------------
+namespace kr {
+int check_minimizer_params(const kr_build_params* bp, BuildCfg& c, LshPositions& lsh)
+{
+  if (!bp || !bp->ppos) return fail(KR_ERR_ARG, "kr_minimizers: parameters with explicit ppos are required");
+  c = BuildCfg{bp->k, bp->w, bp->h, bp->m, bp->r, bp->frac != 0};
+  if (c.k > 31 || c.k < 3 || c.h == 0 || c.h >= c.k || c.k - c.h > 16 || c.h > 15 || c.m == 0 || c.r >= c.m || c.w > 255)
+    return fail(KR_ERR_ARG, "kr_minimizers: unsupported k/w/h/m/r");
+  if (!make_positions(c.k, c.h, bp->ppos, lsh)) return fail(KR_ERR_ARG, "kr_minimizers: bad LSH positions");
+  return KR_OK;
+}
+int finish_minimizers(std::vector<uint64_t>& keys, double n1, double n2, kr_minimizer_result* out)
+{
+  std::sort(keys.begin(), keys.end());
+  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  out->nkeys = keys.size();
+  out->keys = (uint64_t*)malloc(std::max<size_t>(1, keys.size()) * 8);
+  if (!out->keys) return fail(KR_ERR_NOMEM, "kr_minimizers: out of memory");
+  if (!keys.empty()) memcpy(out->keys, keys.data(), keys.size() * 8);
+  out->n1 = n1;
+  out->n2 = n2;
+  return KR_OK;
+}
+} // namespace kr
+
+extern "C" int kr_minimizers_cpu(const kr_build_params* bp, const uint8_t* bases, const uint64_t* offsets, uint32_t ncontigs,
+                                 kr_minimizer_result* out)
+{
+  kr::clear_error();
+  if (!bases || !offsets || !out) return kr::fail(KR_ERR_ARG, "kr_minimizers_cpu: null argument");
+  BuildCfg c;
+  LshPositions lsh;
+  int rc = kr::check_minimizer_params(bp, c, lsh);
+  if (rc) return rc;
+  std::vector<uint64_t> keys;
+  double n1 = 0, n2 = 0;
+  for (uint32_t q = 0; q < ncontigs; ++q) {
+    uint64_t len = offsets[q + 1] - offsets[q];
+    if (len >= c.w) kr::extract_contig_cpu(bases + offsets[q], len, c, lsh, keys, n1, n2);
+  }
+  return kr::finish_minimizers(keys, n1, n2, out);
+}
+
+extern "C" void kr_minimizers_free(kr_minimizer_result* r)
+{
+  if (!r) return;
+  free(r->keys);
+  r->keys = nullptr;
+  r->nkeys = 0;
 }

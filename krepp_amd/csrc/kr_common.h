@@ -35,6 +35,45 @@ void balanced_tree(const std::vector<std::string>& names, HostTree& out);
 uint64_t leaf_name_hash(const std::string& name);
 uint64_t rehash64(uint64_t sh); // Subset::rehash, src/record.hpp:37-47
 
+// ---- index build helpers shared by kr_build.cpp (CPU) and kr_minimizer.hip (GPU) ----
+struct BuildCfg {
+  uint32_t k, w, h, m, r;
+  bool frac;
+};
+struct LshPositions {
+  uint32_t k = 0, h = 0;
+  std::vector<uint8_t> ppos, npos; // descending / ascending
+  std::vector<uint8_t> pasc;       // ppos ascending
+  uint32_t rix(uint64_t bp) const; // closed forms of LSHF::compute_hash / drop_ppos_lr
+  uint32_t enc32(uint64_t bp) const;
+};
+bool make_positions(uint32_t k, uint32_t h, const uint8_t* ppos, LshPositions& out);
+// HyperLogLog(12) estimate from 4096 registers (src/hyperloglog.hpp:113-135)
+double hll12_estimate(const uint8_t* reg);
+// row of a k-mer in a partial library, or -1 (src/rqseq.cpp:125-128)
+inline int64_t build_row(uint32_t rix, const BuildCfg& c)
+{
+  uint32_t res = rix % c.m;
+  if (c.frac ? res <= c.r : res == c.r) return c.frac ? (int64_t)(rix / c.m) * (c.r + 1) + res : (int64_t)(rix / c.m);
+  return -1;
+}
+inline uint64_t fmix64(uint64_t v)
+{ // xur64_hash, src/common.hpp:147-155
+  v ^= v >> 33;
+  v *= 0xff51afd7ed558ccdull;
+  v ^= v >> 33;
+  v *= 0xc4ceb9fe1a85ec53ull;
+  v ^= v >> 33;
+  return v;
+}
+// One contig on the CPU (RSeq::extract_mers): appends keys, adds the contig's HLL estimates.
+void extract_contig_cpu(const uint8_t* seq, uint64_t len, const BuildCfg& c, const LshPositions& lsh,
+                        std::vector<uint64_t>& keys, double& n1, double& n2);
+// What the ring buffer of RSeq::extract_mers yields at the END of a contig whose last run of valid
+// bases is shorter than w (src/rqseq.cpp:108-116: stale or zero slots take part): true if a
+// minimizer is emitted there; `x` is its k-mer code, `z` its hash.
+bool contig_end_special(const uint8_t* seq, uint64_t len, const BuildCfg& c, uint64_t& x, uint64_t& z);
+
 } // namespace kr
 
 #endif

@@ -47,7 +47,7 @@ static const std::map<std::string, std::string> kAlias = {
   {"-i", "--index-dir"}, {"-q", "--query"}, {"-o", "--output-path"}, {"-t", "--nwk-file"}, {"-k", "--kmer-len"},
   {"-w", "--win-len"}, {"-h", "--num-positions"}, {"-m", "--modulo-lsh"}, {"-r", "--residue-lsh"},
 };
-static const char* kFlags[] = {"--multi", "--filter", "--summarize", "--frac", "--verbose"};
+static const char* kFlags[] = {"--multi", "--filter", "--summarize", "--frac", "--verbose", "--gpu-minimizers"};
 
 static Args parse(int argc, char** argv)
 {
@@ -282,6 +282,8 @@ static int run_index(const Args& a)
   if (a.flag.count("--frac")) bp.frac = a.flag.at("--frac");
   bp.num_threads = a.has("--num-threads") ? (uint32_t)atoi(a.get("--num-threads").c_str()) : 1;
   bp.seed = a.has("--seed") ? (uint32_t)atoi(a.get("--seed").c_str()) : 0;
+  bp.gpu_minimizers = a.flag.count("--gpu-minimizers") && a.flag.at("--gpu-minimizers");
+  bp.device = a.has("--device") ? atoi(a.get("--device").c_str()) : 0;
   fprintf(stderr, "Building the index...\n");
   std::string nwk = a.get("--nwk-file");
   if (kr_build_index(input.c_str(), nwk.empty() ? nullptr : nwk.c_str(), outdir.c_str(), &bp)) error_exit(kr_last_error());
