@@ -83,7 +83,7 @@ struct DevIndex {
 };
 
 struct LlhConst {
-  uint32_t k, h, th, pad;
+  uint32_t k, h, th, dbg; // dbg: timing experiments only (KR_DEBUG_LLH): 1 no pow, 2 no log(d)/log(1-d), 4 no final log, 8 short loop
   double binom_k[32];
   double binom_hnk[kMaxPlanes];
 };
@@ -1105,21 +1105,73 @@ struct LlhProblem {
   double uc, rho;
 };
 
-__device__ double llh_eval(const LlhConst& C, const LlhProblem& p, double d)
+// x^n for a small positive integer n in double-double arithmetic (error-free products through fma).
+// The chain carries ~100 bits, so the rounded result is the correctly rounded power except in
+// near-tie cases: the contract of glibc's pow, which the reference calls at src/hdhistllh.hpp:74,
+// and tighter (and ~3x cheaper) than the general-purpose device pow.
+struct DD {
+  double hi, lo;
+};
+__device__ __forceinline__ DD dd_mul(DD a, DD b)
+{
+  double p = a.hi * b.hi;
+  double e = fma(a.hi, b.hi, -p);
+  e = fma(a.hi, b.lo, e);
+  e = fma(a.lo, b.hi, e);
+  double s = p + e;
+  return DD{s, e - (s - p)};
+}
+__device__ __forceinline__ double pown_dd(double x, uint32_t n)
+{
+  DD r{1.0, 0.0}, b{x, 0.0};
+  while (n) {
+    if (n & 1u) r = dd_mul(r, b);
+    n >>= 1;
+    if (n) b = dd_mul(b, b);
+  }
+  return r.hi + r.lo;
+}
+
+typedef KR_LDS double lds_f64;
+struct LlhTables { // per-workgroup copies of the binomial tables (uniform LDS reads, no scalar-load stalls)
+  lds_f64* bk;  // [k+1]
+  lds_f64* hnk; // [th+1]
+};
+__device__ __forceinline__ void llh_tables_init(const LlhConst& C, lds_f64* bk, lds_f64* hnk)
+{
+  for (uint32_t i = threadIdx.x; i <= C.k; i += blockDim.x) bk[i] = C.binom_k[i];
+  for (uint32_t i = threadIdx.x; i <= C.th; i += blockDim.x) hnk[i] = C.binom_hnk[i];
+  __syncthreads();
+}
+
+// HDistHistLLH::operator() (src/hdhistllh.hpp:71-89), same operation order.  NPT = th+1 when known
+// at compile time (histogram in registers), 0 = any th.
+template <int NPT>
+__device__ __forceinline__ double llh_eval(const LlhConst& C, const LlhTables& T, const LlhProblem& p, double d)
 {
   double sum = 0.0, lv_m = 0.0;
-  double powdc = pow(1.0 - d, (double)C.k);
+  double powdc = (C.dbg & 1u) ? pow(1.0 - d, (double)C.k) : pown_dd(1.0 - d, C.k);
   double logdn = log(1.0 - d);
   double logdp = log(d) - logdn;
   logdn *= (double)C.k;
-  double dratio = d / (1.0 - d);
-  for (uint32_t x = 0; x <= C.k; ++x) {
-    if (x <= C.th) {
+  const double dratio = d / (1.0 - d);
+  if (NPT > 0) {
+#pragma unroll
+    for (int x = 0; x < NPT; ++x) {
       sum -= (logdn + (double)x * logdp) * p.mc[x];
-      lv_m += C.binom_hnk[x] * powdc;
-    } else {
-      lv_m += powdc * C.binom_k[x];
+      lv_m += T.hnk[x] * powdc;
+      powdc *= dratio;
     }
+  } else {
+    for (uint32_t x = 0; x <= C.th; ++x) {
+      sum -= (logdn + (double)x * logdp) * p.mc[x];
+      lv_m += T.hnk[x] * powdc;
+      powdc *= dratio;
+    }
+  }
+#pragma unroll 4
+  for (uint32_t x = C.th + 1; x <= C.k; ++x) {
+    lv_m += powdc * T.bk[x];
     powdc *= dratio;
   }
   return sum - log(p.rho * lv_m + 1.0 - p.rho) * p.uc;
@@ -1127,14 +1179,15 @@ __device__ double llh_eval(const LlhConst& C, const LlhProblem& p, double d)
 
 // boost::math::tools::brent_find_minima(f, 1e-10, 0.5, 16) (src/query.cpp:430);
 // published algorithm, see SURVEY.md Appendix B.
-__device__ void brent_min(const LlhConst& C, const LlhProblem& p, double& d_out, double& v_out)
+template <int NPT>
+__device__ __forceinline__ void brent_min(const LlhConst& C, const LlhTables& T, const LlhProblem& p, double& d_out, double& v_out)
 {
   double mn = 1e-10, mx = 0.5;
   const double tolerance = 0x1p-15; // ldexp(1, 1 - min(53/2, 16))
   const double golden = 0.3819660f;
   double x, w, v, u, delta, delta2, fu, fv, fw, fx, mid, fract1, fract2;
   x = w = v = mx;
-  fw = fv = fx = llh_eval(C, p, x);
+  fw = fv = fx = llh_eval<NPT>(C, T, p, x);
   delta2 = delta = 0;
   for (int it = 0; it < 1000; ++it) {
     mid = (mn + mx) / 2;
@@ -1163,7 +1216,7 @@ __device__ void brent_min(const LlhConst& C, const LlhProblem& p, double& d_out,
       delta = golden * delta2;
     }
     u = (fabs(delta) >= fract1) ? (x + delta) : (delta > 0 ? (x + fabs(fract1)) : (x - fabs(fract1)));
-    fu = llh_eval(C, p, u);
+    fu = llh_eval<NPT>(C, T, p, u);
     if (fu <= fx) {
       if (u >= x)
         mn = x;
@@ -1189,19 +1242,29 @@ __device__ void brent_min(const LlhConst& C, const LlhProblem& p, double& d_out,
   v_out = fx;
 }
 
+template <int NPT>
 __device__ __forceinline__ void load_problem(const LlhConst& C, const uint32_t* hist, uint32_t onmers, double rho,
                                              LlhProblem& p)
 {
   uint32_t mc = 0;
-  for (uint32_t x = 0; x <= C.th; ++x) {
-    p.mc[x] = (double)hist[x];
-    mc += hist[x];
+  if (NPT > 0) {
+#pragma unroll
+    for (int x = 0; x < NPT; ++x) {
+      p.mc[x] = (double)hist[x];
+      mc += hist[x];
+    }
+  } else {
+    for (uint32_t x = 0; x <= C.th; ++x) {
+      p.mc[x] = (double)hist[x];
+      mc += hist[x];
+    }
   }
   p.uc = (double)onmers - (double)mc; // mismatch_count = onmers - match_count (src/query.cpp:104)
   p.rho = rho;
 }
 
-__global__ __launch_bounds__(256) void kr_llh_kernel(LlhConst C, DevIndex ix, BatchOut out)
+template <int NPT>
+__device__ __forceinline__ void llh_records(const LlhConst& C, const LlhTables& T, const DevIndex& ix, const BatchOut& out)
 {
   uint32_t nrec = min(out.counters[0], out.rec_cap);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += gridDim.x * blockDim.x) {
@@ -1209,12 +1272,22 @@ __global__ __launch_bounds__(256) void kr_llh_kernel(LlhConst C, DevIndex ix, Ba
     if (key == 0) continue; // hole at the end of a wave's record chunk
     uint32_t read = out.rec_read[i];
     LlhProblem p;
-    load_problem(C, out.rec_hist + (uint64_t)i * (C.th + 1), out.rd_onmers[read], ix.libs[0].rho[key >> 1], p);
+    load_problem<NPT>(C, out.rec_hist + (uint64_t)i * (C.th + 1), out.rd_onmers[read], ix.libs[0].rho[key >> 1], p);
     double d, v;
-    brent_min(C, p, d, v);
+    brent_min<NPT>(C, T, p, d, v);
     out.rec_d[i] = d;
     out.rec_v[i] = v;
   }
+}
+
+// NPT = 5: --hdist-th default, histogram in registers; NPT = 0: any threshold
+template <int NPT>
+__global__ __launch_bounds__(256) void kr_llh_kernel(LlhConst C, DevIndex ix, BatchOut out)
+{
+  __shared__ double s_bk[32], s_hnk[kMaxPlanes];
+  LlhTables T{(lds_f64*)s_bk, (lds_f64*)s_hnk};
+  llh_tables_init(C, T.bk, T.hnk);
+  llh_records<NPT>(C, T, ix, out);
 }
 
 // summarize_matches' strand merge and closest (src/query.cpp:96-139) + the row selection
@@ -1225,6 +1298,9 @@ __global__ __launch_bounds__(256) void kr_llh_kernel(LlhConst C, DevIndex ix, Ba
 __global__ __launch_bounds__(256) void kr_select_kernel(LlhConst C, DevIndex ix, DevParams P, BatchOut out,
                                                         uint32_t nreads)
 {
+  __shared__ double s_bk[32], s_hnk[kMaxPlanes];
+  LlhTables T{(lds_f64*)s_bk, (lds_f64*)s_hnk};
+  llh_tables_init(C, T.bk, T.hnk);
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += gridDim.x * blockDim.x) {
     uint32_t o = out.rd_off[r], n = out.rd_cnt[r];
     // closest: last record in (strand, se) order with d <= best
@@ -1241,8 +1317,8 @@ __global__ __launch_bounds__(256) void kr_select_kernel(LlhConst C, DevIndex ix,
     LlhProblem pc;
     double vcl = 0;
     if (cl >= 0 && !P.no_filter) {
-      load_problem(C, out.rec_hist + (uint64_t)cl * (C.th + 1), out.rd_onmers[r], ix.libs[0].rho[out.rec_key[cl] >> 1],
-                   pc);
+      load_problem<0>(C, out.rec_hist + (uint64_t)cl * (C.th + 1), out.rd_onmers[r], ix.libs[0].rho[out.rec_key[cl] >> 1],
+                      pc);
       vcl = out.rec_v[cl];
     }
     for (uint32_t i = o; i < o + n; ++i) {
@@ -1275,7 +1351,7 @@ __global__ __launch_bounds__(256) void kr_select_kernel(LlhConst C, DevIndex ix,
         } else if (P.no_filter) {
           sel = dm;
         } else {
-          chi = 2 * (llh_eval(C, pc, d) - vcl); // Minfo::likelihood_ratio (src/query.cpp:420-424)
+          chi = 2 * (llh_eval<0>(C, T, pc, d) - vcl); // Minfo::likelihood_ratio (src/query.cpp:420-424)
           sel = (chi < P.chisq) && dm;
         }
       }
@@ -1319,14 +1395,18 @@ __global__ __launch_bounds__(kWave) void kr_front_end_kernel(DevIndex ix, BatchI
   }
 }
 
+template <int NPT>
 __global__ void kr_brent_kernel(LlhConst C, uint32_t n, const uint32_t* hist, const uint32_t* onmers, const double* rho,
                                 double* d_out, double* v_out)
 {
+  __shared__ double s_bk[32], s_hnk[kMaxPlanes];
+  LlhTables T{(lds_f64*)s_bk, (lds_f64*)s_hnk};
+  llh_tables_init(C, T.bk, T.hnk);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   LlhProblem p;
-  load_problem(C, hist + (uint64_t)i * (C.th + 1), onmers[i], rho[i], p);
-  brent_min(C, p, d_out[i], v_out[i]);
+  load_problem<NPT>(C, hist + (uint64_t)i * (C.th + 1), onmers[i], rho[i], p);
+  brent_min<NPT>(C, T, p, d_out[i], v_out[i]);
 }
 
 // Re-layout kernels used by kr_index_upload.
@@ -1391,6 +1471,7 @@ LlhConst make_llh_const(uint32_t k, uint32_t h, uint32_t th)
   LlhConst C;
   memset(&C, 0, sizeof(C));
   C.k = k, C.h = h, C.th = th;
+  C.dbg = getenv("KR_DEBUG_LLH") ? (uint32_t)atoi(getenv("KR_DEBUG_LLH")) : 0u;
   uint64_t bk[32] = {0};
   bk[0] = 1;
   for (uint32_t i = 0; i < k; ++i) bk[i + 1] = (bk[i] * (k - i)) / (i + 1);
@@ -1922,7 +2003,10 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
     HIP_TRY(hipEventRecord(s->ev[2], st));
   }
   HIP_TRY(hipEventRecord(s->ev[3], st));
-  hipLaunchKernelGGL(kr_llh_kernel, dim3(1024), dim3(256), 0, st, s->llh, dix, s->out);
+  if (s->llh.th == 4)
+    hipLaunchKernelGGL(kr_llh_kernel<5>, dim3(2048), dim3(256), 0, st, s->llh, dix, s->out);
+  else
+    hipLaunchKernelGGL(kr_llh_kernel<0>, dim3(2048), dim3(256), 0, st, s->llh, dix, s->out);
   hipLaunchKernelGGL(kr_select_kernel, dim3((nreads + 255) / 256), dim3(256), 0, st, s->llh, dix, s->dp, s->out, nreads);
   HIP_TRY(hipEventRecord(s->ev[4], st));
   HIP_TRY(hipGetLastError());
@@ -2095,7 +2179,10 @@ int kr_debug_brent(const kr_index* ix, uint32_t th, uint32_t n, const uint32_t* 
   HIP_TRY(hipMemcpy(d_h, hist, (uint64_t)n * (th + 1) * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_on, onmers, (uint64_t)n * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_rho, rho, (uint64_t)n * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(kr_brent_kernel, dim3((n + 127) / 128), dim3(128), 0, 0, C, n, d_h, d_on, d_rho, d_d, d_v);
+  if (th == 4)
+    hipLaunchKernelGGL(kr_brent_kernel<5>, dim3((n + 127) / 128), dim3(128), 0, 0, C, n, d_h, d_on, d_rho, d_d, d_v);
+  else
+    hipLaunchKernelGGL(kr_brent_kernel<0>, dim3((n + 127) / 128), dim3(128), 0, 0, C, n, d_h, d_on, d_rho, d_d, d_v);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(d_out, d_d, (uint64_t)n * 8, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(v_out, d_v, (uint64_t)n * 8, hipMemcpyDeviceToHost));
