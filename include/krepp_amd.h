@@ -90,6 +90,8 @@ KR_API void kr_host_index_free(kr_host_index*);
 KR_API int kr_host_index_view(const kr_host_index*, kr_index_view* out);
 /* Node::get_name (src/phytree.hpp:134-145): label, or se-1 for unlabelled nodes. */
 KR_API const char* kr_host_index_node_name(const kr_host_index*, uint32_t se);
+/* the label as written in the Newick / reflist ("" for unlabelled nodes) */
+KR_API const char* kr_host_index_node_label(const kr_host_index*, uint32_t se);
 KR_API uint32_t kr_host_index_node_parent(const kr_host_index*, uint32_t se);
 KR_API double kr_host_index_node_blen(const kr_host_index*, uint32_t se);
 
@@ -216,6 +218,14 @@ KR_API int kr_debug_front_end(const kr_index*, const uint8_t* bases, const uint6
 KR_API int kr_debug_brent(const kr_index*, uint32_t hdist_th, uint32_t n, const uint32_t* hist /*[n*(th+1)]*/,
                           const uint32_t* onmers, const double* rho, double* d_out, double* v_out);
 
+/* Likelihood kernel on arbitrary problems (the per-edge likelihoods of `krepp place`, whose
+ * histograms are fractional: Minfo::add, src/query.hpp:139-152).  One problem per element:
+ * hist[n*(th+1)] (doubles), uc[n] = mismatch_count, rho[n].  mode 0: Brent minimisation
+ * (Minfo::optimize_likelihood, src/query.cpp:426-433) -> d_out, v_out.  mode 1: evaluate f at
+ * d_in[n] -> v_out (Minfo::likelihood_ratio's f(d), src/query.cpp:420-424). */
+KR_API int kr_llh_batch(const kr_index*, uint32_t hdist_th, uint32_t mode, uint64_t n, const double* hist, const double* uc,
+                        const double* rho, const double* d_in, double* d_out, double* v_out);
+
 /* Kernel timing of the last collected batch (HIP events on the stream's own stream). */
 typedef struct kr_timing {
   float ms_total;    /* first kernel start -> last kernel end                        */
@@ -248,6 +258,38 @@ KR_API void kr_fastx_close(kr_fastx*);
 KR_API int kr_format_dist(const kr_host_index*, const kr_result_view*, const char* const* names, char** text,
                           uint64_t* len);
 KR_API void kr_free(void*);
+
+/* ------------------------------------------------------------------------- */
+/* `krepp place`: IBatch::place_sequences / report_placement (src/query.cpp:198-333), */
+/* TargetIndex::ensure_backbone (src/krepp.cpp:48-64), Tree::map_to_qtree /           */
+/* compute_eff_nchildren (src/phytree.cpp:421-473).  Lineage files (-l) are not built. */
+/* ------------------------------------------------------------------------- */
+typedef struct kr_place_tree kr_place_tree;
+/* nwk_text == NULL: place on the index's own backbone; otherwise map the index leaves onto the
+ * given rooted Newick tree.  kr_place_tree_kinds gives the node_kind array to upload the index
+ * with (leaves absent from the placement tree become null nodes, as after map_to_qtree). */
+KR_API int kr_place_tree_create(const kr_host_index*, const char* nwk_text, kr_place_tree** out);
+KR_API void kr_place_tree_free(kr_place_tree*);
+KR_API const uint8_t* kr_place_tree_kinds(const kr_place_tree*);
+
+typedef struct kr_placement {
+  uint32_t read;
+  uint32_t edge;  /* Node::get_en = se - 1 in the placement tree */
+  double lwr, d_llh, v_llh, pendant, distal;
+} kr_placement;
+
+/* Back end for one collected batch.  `rv` must come from kr_batch_collect of a stream created with
+ * multi = 1, no_filter = 1, dist_max unset, submitted with KR_TAP_ACCS (it needs the histograms);
+ * `p` carries the place options (tau, chisq, multi, no_filter; filter defaults to on for place,
+ * src/krepp.cpp:593-630).  The tree aggregation runs on the host; every likelihood (Brent on the
+ * fractional histograms of internal nodes, the chi-square evaluations) runs on the GPU through
+ * kr_llh_batch.  `has_previous` carries the jplace comma state across batches (in/out). */
+KR_API int kr_place_batch(const kr_host_index*, const kr_index*, const kr_place_tree*, const kr_result_view* rv,
+                          const uint64_t* offsets, const char* const* names, const kr_params* p, int tabular,
+                          int* has_previous, char** text, uint64_t* len, kr_placement** placements, uint64_t* nplacements);
+/* which = 0: text before the batches (jplace opening / tabular header), 1: after (jplace metadata + tree) */
+KR_API int kr_place_frame(const kr_place_tree*, int which, int tabular, const char* invocation, uint64_t total_qseq,
+                          char** text, uint64_t* len);
 
 /* CPU-side index construction (`krepp index`, src/krepp.cpp:131-303): stays on the
  * CPU as in the reference; needed to make any index at all. */

@@ -83,11 +83,12 @@ class KrBuildParams(C.Structure):
 # every symbol include/krepp_amd.h declares (tests check that the library exports them all)
 EXPORTS = [
     "kr_host_index_load", "kr_host_index_free", "kr_host_index_view", "kr_host_index_node_name",
-    "kr_host_index_node_parent", "kr_host_index_node_blen",
+    "kr_host_index_node_label", "kr_host_index_node_parent", "kr_host_index_node_blen",
     "kr_index_upload", "kr_index_free", "kr_index_export", "kr_index_import", "kr_index_device_bytes",
     "kr_params_default", "kr_stream_create", "kr_stream_destroy", "kr_batch_submit", "kr_batch_wait",
     "kr_batch_collect", "kr_batch_collect_device", "kr_batch_hits", "kr_batch_readtaps",
-    "kr_debug_front_end", "kr_debug_brent", "kr_batch_timing",
+    "kr_debug_front_end", "kr_debug_brent", "kr_llh_batch", "kr_batch_timing",
+    "kr_place_tree_create", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_frame",
     "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_format_dist", "kr_free",
     "kr_build_index", "kr_minimizers_cpu", "kr_minimizers_device", "kr_minimizers_free", "kr_last_error", "kr_version",
 ]
@@ -119,6 +120,8 @@ def load():
     lib.kr_host_index_view.argtypes = [vp, C.POINTER(KrIndexView)]
     lib.kr_host_index_node_name.argtypes = [vp, C.c_uint32]
     lib.kr_host_index_node_name.restype = C.c_char_p
+    lib.kr_host_index_node_label.argtypes = [vp, C.c_uint32]
+    lib.kr_host_index_node_label.restype = C.c_char_p
     lib.kr_host_index_node_parent.argtypes = [vp, C.c_uint32]
     lib.kr_host_index_node_parent.restype = C.c_uint32
     lib.kr_host_index_node_blen.argtypes = [vp, C.c_uint32]
@@ -144,6 +147,15 @@ def load():
     lib.kr_debug_front_end.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     lib.kr_debug_brent.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]
     lib.kr_batch_timing.argtypes = [vp, C.POINTER(KrTiming)]
+    lib.kr_llh_batch.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp, vp]
+    lib.kr_place_tree_create.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+    lib.kr_place_tree_free.argtypes = [vp]
+    lib.kr_place_tree_free.restype = None
+    lib.kr_place_tree_kinds.argtypes = [vp]
+    lib.kr_place_tree_kinds.restype = u8p
+    lib.kr_place_batch.argtypes = [vp, vp, vp, C.POINTER(KrResultView), vp, C.POINTER(C.c_char_p), C.POINTER(KrParams), C.c_int,
+                                   C.POINTER(C.c_int), C.POINTER(vp), u64p, C.POINTER(vp), u64p]
+    lib.kr_place_frame.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_uint64, C.POINTER(vp), u64p]
     lib.kr_fastx_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.kr_fastx_next.argtypes = [vp, C.c_uint64, C.POINTER(KrFastxBatch)]
     lib.kr_fastx_close.argtypes = [vp]
@@ -476,3 +488,58 @@ def minimizers(bases, offsets, k, w, h, ppos, m=4, r=1, frac=True, device=None):
     out = (keys, res.n1, res.n2)
     lib.kr_minimizers_free(C.byref(res))
     return out
+
+
+PLACEMENT_DT = np.dtype([("read", "<u4"), ("edge", "<u4"), ("lwr", "<f8"), ("d_llh", "<f8"), ("v_llh", "<f8"),
+                         ("pendant", "<f8"), ("distal", "<f8")])
+
+
+class Placer:
+    """`krepp place` on one GPU: placement tree + device index (uploaded with the tree's node kinds) + stream."""
+
+    def __init__(self, host_index, nwk_text=None, device=0, tabular=False, max_reads=1 << 16, max_bases=None, **place_opts):
+        self.lib = load()
+        self.hx = host_index
+        self.tabular = tabular
+        self.pt = C.c_void_p()
+        check(self.lib.kr_place_tree_create(host_index.h, nwk_text.encode() if nwk_text is not None else None, C.byref(self.pt)))
+        view = KrIndexView()
+        C.memmove(C.byref(view), C.byref(host_index.view), C.sizeof(view))
+        view.node_kind = self.lib.kr_place_tree_kinds(self.pt)
+        self.dx = DeviceIndex.from_view(view, device, KR_VIEW_HOST, keep=host_index)
+        # options of `place` (filter defaults to on: src/krepp.cpp:593-630)
+        self.popts = default_params(no_filter=0, **place_opts)
+        front = default_params(hdist_th=self.popts.hdist_th)  # multi, no_filter, no dist-max: every chosen leaf
+        self.st = self.dx.stream(params=front, max_reads=max_reads, max_bases=max_bases, max_records=max_reads * 128)
+        self.prev = C.c_int(0)
+
+    def frame(self, which, invocation="", total=0):
+        txt, ln = C.c_void_p(), C.c_uint64()
+        check(self.lib.kr_place_frame(self.pt, which, int(self.tabular), invocation.encode(), total, C.byref(txt), C.byref(ln)))
+        s = C.string_at(txt, ln.value).decode()
+        self.lib.kr_free(txt)
+        return s
+
+    def place(self, bases, offsets, names):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.st.submit(bases, offsets, KR_TAP_ACCS)
+        rv = KrResultView()
+        check(self.lib.kr_batch_collect(self.st.h, C.byref(rv)))
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        txt, ln, pls, npl = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64()
+        check(self.lib.kr_place_batch(self.hx.h, self.dx.h, self.pt, C.byref(rv), offsets.ctypes.data, arr, C.byref(self.popts),
+                                      int(self.tabular), C.byref(self.prev), C.byref(txt), C.byref(ln), C.byref(pls), C.byref(npl)))
+        text = C.string_at(txt, ln.value).decode()
+        pl = (np.frombuffer(C.string_at(pls, npl.value * PLACEMENT_DT.itemsize), dtype=PLACEMENT_DT).copy()
+              if npl.value else np.zeros(0, PLACEMENT_DT))
+        self.lib.kr_free(txt)
+        self.lib.kr_free(pls)
+        return text, pl
+
+    def close(self):
+        if self.pt:
+            self.st.close()
+            self.dx.close()
+            self.lib.kr_place_tree_free(self.pt)
+            self.pt = C.c_void_p()

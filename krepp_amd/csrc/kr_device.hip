@@ -1409,6 +1409,29 @@ __global__ void kr_brent_kernel(LlhConst C, uint32_t n, const uint32_t* hist, co
   brent_min<NPT>(C, T, p, d_out[i], v_out[i]);
 }
 
+__global__ __launch_bounds__(256) void kr_llh_batch_kernel(LlhConst C, uint32_t mode, uint64_t n, const double* hist,
+                                                           const double* uc, const double* rho, const double* d_in,
+                                                           double* d_out, double* v_out)
+{
+  __shared__ double s_bk[32], s_hnk[kMaxPlanes];
+  LlhTables T{(lds_f64*)s_bk, (lds_f64*)s_hnk};
+  llh_tables_init(C, T.bk, T.hnk);
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    LlhProblem p;
+    for (uint32_t x = 0; x <= C.th; ++x) p.mc[x] = hist[i * (C.th + 1) + x];
+    p.uc = uc[i];
+    p.rho = rho[i];
+    if (mode == 0) {
+      double d, v;
+      brent_min<0>(C, T, p, d, v);
+      d_out[i] = d;
+      v_out[i] = v;
+    } else {
+      v_out[i] = llh_eval<0>(C, T, p, d_in[i]);
+    }
+  }
+}
+
 // Re-layout kernels used by kr_index_upload.
 // class of a colour id: 0 drop, 1 leaf, 2 expand (see colour_needs_expansion)
 __device__ __forceinline__ uint32_t tag_colour(uint32_t se, const uint32_t* node_info, uint32_t tree_nnodes, uint32_t nsubsets)
@@ -2159,6 +2182,37 @@ int kr_debug_front_end(const kr_index* ix, const uint8_t* bases, const uint64_t*
   HIP_TRY(hipMemcpy(valid, d_valid, n, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(pass, d_pass, n, hipMemcpyDeviceToHost));
   hipFree(d_b), hipFree(d_o), hipFree(d_rix), hipFree(d_enc), hipFree(d_valid), hipFree(d_pass);
+  return KR_OK;
+}
+
+int kr_llh_batch(const kr_index* ix, uint32_t th, uint32_t mode, uint64_t n, const double* hist, const double* uc, const double* rho,
+                 const double* d_in, double* d_out, double* v_out)
+{
+  kr::clear_error();
+  if (!ix || th > KR_MAX_HDIST_TH || mode > 1 || (n && (!hist || !uc || !rho || !v_out)) || (mode == 0 && n && !d_out) ||
+      (mode == 1 && n && !d_in))
+    return kr::fail(KR_ERR_ARG, "kr_llh_batch: bad argument");
+  if (n == 0) return KR_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  LlhConst C = make_llh_const(ix->dix.k, ix->dix.h, th);
+  double *d_h = nullptr, *d_uc = nullptr, *d_rho = nullptr, *d_di = nullptr, *d_do = nullptr, *d_v = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_h, n * (th + 1) * 8));
+  HIP_TRY(hipMalloc((void**)&d_uc, n * 8));
+  HIP_TRY(hipMalloc((void**)&d_rho, n * 8));
+  HIP_TRY(hipMalloc((void**)&d_di, n * 8));
+  HIP_TRY(hipMalloc((void**)&d_do, n * 8));
+  HIP_TRY(hipMalloc((void**)&d_v, n * 8));
+  HIP_TRY(hipMemcpy(d_h, hist, n * (th + 1) * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_uc, uc, n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_rho, rho, n * 8, hipMemcpyHostToDevice));
+  if (mode == 1) HIP_TRY(hipMemcpy(d_di, d_in, n * 8, hipMemcpyHostToDevice));
+  uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(kr_llh_batch_kernel, dim3(grid), dim3(256), 0, 0, C, mode, n, d_h, d_uc, d_rho, d_di, d_do, d_v);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  if (mode == 0) HIP_TRY(hipMemcpy(d_out, d_do, n * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(v_out, d_v, n * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(d_h), (void)hipFree(d_uc), (void)hipFree(d_rho), (void)hipFree(d_di), (void)hipFree(d_do), (void)hipFree(d_v);
   return KR_OK;
 }
 

@@ -508,6 +508,10 @@ const char* kr_host_index_node_name(const kr_host_index* h, uint32_t se)
 {
   return (h && se < h->names.size()) ? h->names[se].c_str() : "";
 }
+const char* kr_host_index_node_label(const kr_host_index* h, uint32_t se)
+{
+  return (h && se < h->tree.nodes.size()) ? h->tree.nodes[se].label.c_str() : "";
+}
 uint32_t kr_host_index_node_parent(const kr_host_index* h, uint32_t se)
 {
   return (h && se < h->tree.nodes.size()) ? h->tree.nodes[se].parent : 0;

@@ -45,9 +45,9 @@ struct Args {
 
 static const std::map<std::string, std::string> kAlias = {
   {"-i", "--index-dir"}, {"-q", "--query"}, {"-o", "--output-path"}, {"-t", "--nwk-file"}, {"-k", "--kmer-len"},
-  {"-w", "--win-len"}, {"-h", "--num-positions"}, {"-m", "--modulo-lsh"}, {"-r", "--residue-lsh"},
+  {"-w", "--win-len"}, {"-h", "--num-positions"}, {"-m", "--modulo-lsh"}, {"-r", "--residue-lsh"}, {"-l", "--lineage-file"},
 };
-static const char* kFlags[] = {"--multi", "--filter", "--summarize", "--frac", "--verbose", "--gpu-minimizers"};
+static const char* kFlags[] = {"--multi", "--filter", "--summarize", "--frac", "--verbose", "--gpu-minimizers", "--tabular"};
 
 static Args parse(int argc, char** argv)
 {
@@ -91,9 +91,11 @@ struct Job {
   bool done = false;
 };
 
-static int run_dist(const Args& a, const std::string& invocation)
+// `dist` and `place` share everything up to the per-batch back end (src/krepp.cpp:347-394, 434-504)
+static int run_query(const Args& a, const std::string& invocation, bool place)
 {
-  if (!a.has("--query") || !a.has("--index-dir")) error_exit("dist requires -q/--query and -i/--index-dir");
+  if (!a.has("--query") || !a.has("--index-dir")) error_exit("dist/place require -q/--query and -i/--index-dir");
+  if (a.has("--lineage-file")) error_exit("-l/--lineage-file is not implemented in this build (use -t or the index's backbone)");
   if (a.flag.count("--summarize") && a.flag.at("--summarize"))
     error_exit("--summarize is not implemented in this build");
   kr_params p;
@@ -105,7 +107,11 @@ static int run_dist(const Args& a, const std::string& invocation)
     if (!(p.dist_max >= 1e-8 && p.dist_max <= 0.33)) error_exit("--dist-max: value not in range [1e-08, 0.33]");
   }
   if (a.flag.count("--multi")) p.multi = a.flag.at("--multi");
+  if (place) p.no_filter = 0; // filter defaults to on for place (src/krepp.cpp:612-615)
   if (a.flag.count("--filter")) p.no_filter = !a.flag.at("--filter");
+  if (a.has("--tau")) p.tau = (uint32_t)atoi(a.get("--tau").c_str());
+  if (place && p.hdist_th < p.tau) error_exit("The threshold tau must be less than HD threshold --hdist-th!");
+  const bool tabular = a.flag.count("--tabular") && a.flag.at("--tabular");
   int ngpus = a.has("--gpus") ? atoi(a.get("--gpus").c_str()) : 1;
   int dev0 = a.has("--device") ? atoi(a.get("--device").c_str()) : 0;
   if (ngpus < 1) ngpus = 1;
@@ -120,14 +126,40 @@ static int run_dist(const Args& a, const std::string& invocation)
   if (kr_host_index_load(a.get("--index-dir").c_str(), &hx)) error_exit(kr_last_error());
   kr_index_view view;
   kr_host_index_view(hx, &view);
+  kr_place_tree* ptree = nullptr;
+  if (place) {
+    std::string nwk_text;
+    if (a.has("--nwk-file")) {
+      FILE* tf = fopen(a.get("--nwk-file").c_str(), "rb");
+      if (!tf) error_exit("Error opening " + a.get("--nwk-file"));
+      char buf[65536];
+      size_t n;
+      while ((n = fread(buf, 1, sizeof(buf), tf)) > 0) nwk_text.append(buf, n);
+      fclose(tf);
+    }
+    if (kr_place_tree_create(hx, a.has("--nwk-file") ? nwk_text.c_str() : nullptr, &ptree)) error_exit(kr_last_error());
+    view.node_kind = kr_place_tree_kinds(ptree); // leaves absent from the placement tree become null nodes
+    fprintf(stderr, "Placing given sequences on the backbone tree...\n");
+  }
   std::vector<kr_index*> dix(ngpus, nullptr);
   for (int g = 0; g < ngpus; ++g)
     if (kr_index_upload(&view, dev0 + g, KR_VIEW_HOST, &dix[g])) error_exit(kr_last_error());
-  fprintf(stderr, "Estimating distances between given sequences and references...\n");
+  if (!place) fprintf(stderr, "Estimating distances between given sequences and references...\n");
   auto t0 = std::chrono::steady_clock::now();
-  // header (src/krepp.cpp:311-319)
-  fprintf(out, "# software: krepp\tversion: " KREPP_VERSION "\tinvocation :%s\nSEQ_ID\tREFERENCE_NAME\tDIST\n",
-          invocation.c_str());
+  if (!place) { // header (src/krepp.cpp:311-319)
+    fprintf(out, "# software: krepp\tversion: " KREPP_VERSION "\tinvocation :%s\nSEQ_ID\tREFERENCE_NAME\tDIST\n",
+            invocation.c_str());
+  } else { // jplace opening or tabular header (src/krepp.cpp:440-447)
+    char* t = nullptr;
+    uint64_t l = 0;
+    if (kr_place_frame(ptree, 0, tabular, invocation.c_str(), 0, &t, &l)) error_exit(kr_last_error());
+    fwrite(t, 1, l, out);
+    kr_free(t);
+  }
+  // the device front end of `place` keeps every chosen leaf: the place options act in the back end
+  kr_params pfront;
+  kr_params_default(&pfront);
+  pfront.hdist_th = p.hdist_th;
 
   const uint32_t max_reads = 1u << 16;
   const uint64_t batch_bases = (uint64_t)max_reads * 150, max_bases = batch_bases * 4;
@@ -141,7 +173,7 @@ static int run_dist(const Args& a, const std::string& invocation)
 
   auto worker = [&](int g) {
     kr_stream* st = nullptr;
-    if (kr_stream_create(dix[g], &p, max_reads, max_bases, 0, &st)) {
+    if (kr_stream_create(dix[g], place ? &pfront : &p, max_reads, max_bases, place ? (uint64_t)max_reads * 128 : 0, &st)) {
       std::lock_guard<std::mutex> lk(mu);
       worker_err = kr_last_error();
       cv_done.notify_all();
@@ -162,9 +194,14 @@ static int run_dist(const Args& a, const std::string& invocation)
       kr_result_view rv;
       char* txt = nullptr;
       uint64_t len = 0;
-      int rc = kr_batch_submit(st, j->bases.data(), j->offsets.data(), (uint32_t)j->names.size(), KR_BASES_HOST);
+      int rc = kr_batch_submit(st, j->bases.data(), j->offsets.data(), (uint32_t)j->names.size(),
+                               KR_BASES_HOST | (place ? KR_TAP_ACCS : 0u));
       if (!rc) rc = kr_batch_collect(st, &rv);
-      if (!rc) rc = kr_format_dist(hx, &rv, nm.data(), &txt, &len);
+      if (!rc && !place) rc = kr_format_dist(hx, &rv, nm.data(), &txt, &len);
+      if (!rc && place) {
+        int prev = 0; // batches are joined by the writer (src/krepp.cpp:474-484)
+        rc = kr_place_batch(hx, dix[g], ptree, &rv, j->offsets.data(), nm.data(), &p, tabular, &prev, &txt, &len, nullptr, nullptr);
+      }
       std::lock_guard<std::mutex> lk(mu);
       if (rc) {
         worker_err = kr_last_error();
@@ -181,6 +218,7 @@ static int run_dist(const Args& a, const std::string& invocation)
   std::vector<std::thread> workers;
   for (int g = 0; g < ngpus; ++g) workers.emplace_back(worker, g);
 
+  bool jplace_prev = false;
   std::thread writer([&] {
     uint64_t next = 0;
     for (;;) {
@@ -194,7 +232,15 @@ static int run_dist(const Args& a, const std::string& invocation)
         j = it->second;
         finished.erase(it);
       }
-      fwrite(j->text.data(), 1, j->text.size(), out);
+      if (place && !tabular) {
+        if (!j->text.empty()) {
+          if (jplace_prev) fputs(",\n", out);
+          fwrite(j->text.data(), 1, j->text.size(), out);
+          jplace_prev = true;
+        }
+      } else {
+        fwrite(j->text.data(), 1, j->text.size(), out);
+      }
       delete j;
       ++next;
       cv_work.notify_all();
@@ -243,11 +289,19 @@ static int run_dist(const Args& a, const std::string& invocation)
   cv_done.notify_all();
   writer.join();
   if (!worker_err.empty()) error_exit(worker_err);
+  if (place) {
+    char* t = nullptr;
+    uint64_t l = 0;
+    if (kr_place_frame(ptree, 1, tabular, invocation.c_str(), nreads_total, &t, &l)) error_exit(kr_last_error());
+    fwrite(t, 1, l, out);
+    kr_free(t);
+    kr_place_tree_free(ptree);
+  }
   if (out != stdout) fclose(out);
   for (auto* d : dix) kr_index_free(d);
   kr_host_index_free(hx);
   double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  fprintf(stderr, "Done estimating distances, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n", sec,
+  fprintf(stderr, place ? "Done placing queries, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n" : "Done estimating distances, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n", sec,
           sec > 0 ? nreads_total / sec : 0.0, ngpus);
   fprintf(stderr, "Total number of sequences queried: %llu\n", (unsigned long long)nreads_total);
   return 0;
@@ -301,13 +355,15 @@ int main(int argc, char** argv)
   fprintf(stderr, "Invocation: %s\n%s", invocation.c_str(), std::ctime(&now));
   int rc;
   if (a.sub == "dist")
-    rc = run_dist(a, invocation);
+    rc = run_query(a, invocation, false);
+  else if (a.sub == "place")
+    rc = run_query(a, invocation, true);
   else if (a.sub == "index")
     rc = run_index(a);
-  else if (a.sub == "place" || a.sub == "seek" || a.sub == "sketch" || a.sub == "inspect")
-    error_exit("sub-command `" + a.sub + "` is outside the scope of this build (dist/index only)");
+  else if (a.sub == "seek" || a.sub == "sketch" || a.sub == "inspect")
+    error_exit("sub-command `" + a.sub + "` is outside the scope of this build (dist/place/index only)");
   else
-    error_exit("A subcommand is required (dist | index)");
+    error_exit("A subcommand is required (dist | place | index)");
   now = std::time(nullptr);
   fprintf(stderr, "%s", std::ctime(&now));
   return rc;

@@ -27,6 +27,7 @@
 #include <dirent.h>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <queue>
 #include <set>
 #include <sstream>
@@ -227,6 +228,8 @@ struct TNode {
   uint32_t se = 0;
   int parent = -1;
   std::vector<int> children;
+  uint32_t card = 0;          // leaves below (Node::add_children, src/phytree.hpp:107-116)
+  uint32_t eff_nchildren = 0; // children with a mapped leaf below (Tree::compute_eff_nchildren)
 };
 
 struct Tree {
@@ -463,6 +466,10 @@ struct ko_index {
   std::map<uint32_t, uint32_t> r_to_numerator; // src/index.hpp:42
   std::vector<std::string> names;              // cached get_name per se
   std::vector<uint8_t> kind;                   // 0 null, 1 leaf, 2 internal
+  // placement tree (`place`): the backbone itself, or a user tree the index leaves are mapped onto
+  Tree ptree;
+  bool have_ptree = false;
+  std::vector<int> se_to_pnode; // index colour id of a leaf -> node of ptree, or -1
 };
 
 namespace {
@@ -710,6 +717,7 @@ struct Minfo {
   uint32_t rmatch_count = 0, last_pos = 0, last_hdist = 0xFFFFFFFFu, hdist_min = 0xFFFFFFFFu;
   std::vector<double> hist;
   double chisq = NAN, v_llh = NAN, d_llh = DBL_MAX;
+  double lwr = 1; // src/query.hpp:225
   uint32_t strand = 0;
   bool passed = false;
 
@@ -738,6 +746,27 @@ struct Minfo {
     }
     if (hd < hdist_min) hdist_min = hd;
   }
+  // add (src/query.hpp:139-152): weighted accumulation of a descendant leaf into an ancestor
+  void add(const Minfo& m, double denom)
+  {
+    mismatch_count = nmers ? mismatch_count : m.nmers;
+    match_count += m.match_count * denom;
+    mismatch_count -= m.match_count * denom;
+    for (size_t x = 0; x < hist.size(); ++x) hist[x] = hist[x] + m.hist[x] * denom;
+    hdist_min = std::min(hdist_min, m.hdist_min);
+    nmers = std::max(nmers, m.nmers);
+    rho = std::max(rho, m.rho);
+    rmatch_count++;
+  }
+  // get_leq_tau (src/query.hpp:189-196)
+  double get_leq_tau(uint32_t tau) const
+  {
+    double t = 0.0;
+    for (uint32_t x = 0; x <= tau && x < hist.size(); ++x) t += hist[x];
+    return t;
+  }
+  // jukes_cantor_dist (src/query.hpp:197; CJC = 4.0 / 3.0, src/query.hpp:11)
+  double jukes_cantor_dist() const { return -0.75 * log(1 - 4.0 / 3.0 * d_llh); }
   // optimize_likelihood (src/query.cpp:426-433)
   void optimize_likelihood(Llh& f, ko_counters& c)
   {
@@ -773,6 +802,9 @@ struct Worker {
   std::vector<ko_hit> hits;
   std::string text;
   uint32_t read_ix = 0;
+  // place mode (IBatch::place_sequences, src/query.cpp:198-216)
+  bool place_mode = false, tabular = false, has_previous = false;
+  std::vector<ko_placement> placements;
 
   Worker(const ko_index* ix_, const ko_params& p_)
     : ix(ix_), p(p_)
@@ -821,10 +853,10 @@ struct Worker {
         uint32_t se = se_q.front();
         se_q.pop();
         if (tree.check_node(se)) {
-          int nd = tree.get_node(se);
-          if (nd < 0) {
+          int kd = ix->kind[se]; // 0: Tree::get_node(se) == nullptr, 1: leaf, 2: internal
+          if (kd == 0) {
             continue;
-          } else if (tree.nodes[nd].is_leaf) {
+          } else if (kd == 1) {
             auto it = im.leaf_to_minfo.find(se);
             if (it == im.leaf_to_minfo.end()) {
               c.rho_reads++;
@@ -876,6 +908,130 @@ struct Worker {
         add_matching_mer(im_rc, 1, (uint32_t)(len - i), i - k, rcrix, lsh.drop_ppos_lr(conv_bp64_lr64(rcenc64_bp)));
     }
     return onmers;
+  }
+
+  // fixed, precision-5 number as the reference's stringstream prints it (src/query.cpp:208-209)
+  static std::string f5(double v)
+  {
+    char b[64];
+    if (std::isnan(v)) return v < 0 || std::signbit(v) ? "-nan" : "nan";
+    snprintf(b, sizeof(b), "%.5f", v);
+    return b;
+  }
+
+  // IBatch::report_placement (src/query.cpp:218-333); macros PP_JPLACE_FIELDS / PP_TABULAR_FIELDS
+  // (src/query.hpp:202-206).  Maps are keyed by placement-tree node id (the reference keys by pointer).
+  bool report_placement(std::map<uint32_t, Minfo*>& node_to_minfo, uint32_t nd_closest, Minfo* mi_closest, const char* name)
+  {
+    const Tree& pt = ix->ptree;
+    if (node_to_minfo.size() == 0 || !(p.no_filter || (mi_closest->get_leq_tau(p.tau) > 1.0))) return false;
+    std::string id = name ? name : "";
+    auto pnode = [&](uint32_t se) { return ix->se_to_pnode[se]; };
+    auto en = [&](int nd) { return pt.nodes[nd].se - 1; };
+    auto midpoint = [&](int nd) { return std::isnan(pt.nodes[nd].blen) ? 0.0 : pt.nodes[nd].blen / 2.0; };
+    auto jplace_fields = [&](int nd, const Minfo& mi) {
+      return "[" + std::to_string(en(nd)) + ", " + f5(mi.jukes_cantor_dist() - midpoint(nd)) + ", " + f5(midpoint(nd)) + ", " +
+             f5(-mi.v_llh) + ", " + f5(mi.lwr) + ", " + f5(mi.d_llh) + "]";
+    };
+    auto tabular_fields = [&](int nd, const Minfo& mi) {
+      const std::string& nm = pt.nodes[nd].name;
+      return (nm.empty() ? std::string("NA") : nm) + "\t" + std::to_string(en(nd)) + "\t" + f5(mi.lwr) + "\t" + f5(mi.d_llh);
+    };
+    auto record = [&](int nd, const Minfo& mi) {
+      ko_placement pl;
+      pl.read = read_ix, pl.edge = en(nd), pl.lwr = mi.lwr, pl.d_llh = mi.d_llh, pl.v_llh = mi.v_llh;
+      pl.pendant = mi.jukes_cantor_dist() - midpoint(nd), pl.distal = midpoint(nd);
+      placements.push_back(pl);
+    };
+    int nd_pp = pnode(nd_closest);
+    Minfo* mi_pp = mi_closest;
+    mi_pp->chisq = 0;
+    if (!tabular) {
+      if (has_previous) text += ",\n";
+      text += "\t\t\t{\"n\" : [\"" + id + "\"], \"p\" : [";
+    }
+    if (node_to_minfo.size() == 1) {
+      record(nd_pp, *mi_pp);
+      if (tabular)
+        text += id + "\t" + tabular_fields(nd_pp, *mi_pp) + "\n";
+      else
+        text += jplace_fields(nd_pp, *mi_pp) + "]}";
+      return true;
+    }
+    // keyed by (se, node id): iteration in ascending edge number (the reference's order is arbitrary)
+    std::map<std::pair<uint32_t, int>, Minfo*> pp_map_se;
+    std::map<int, Minfo*> pp_map;
+    std::vector<std::unique_ptr<Minfo>> owned;
+    for (auto& kv : node_to_minfo) {
+      int nd_curr = pnode(kv.first);
+      Minfo* mi_curr = kv.second;
+      pp_map[nd_curr] = mi_curr;
+      double denom = 1.0;
+      int nd_parent = nd_curr;
+      while ((nd_parent = pt.nodes[nd_parent].parent) >= 0) {
+        // check_taxon() is false without a lineage file (-l is not restated): always the else branch
+        denom /= pt.nodes[nd_parent].eff_nchildren;
+        if (!pp_map.count(nd_parent)) {
+          owned.emplace_back(new Minfo(p.hdist_th));
+          pp_map[nd_parent] = owned.back().get();
+        }
+        pp_map[nd_parent]->add(*mi_curr, denom);
+      }
+    }
+    for (auto& kv : pp_map) pp_map_se[std::make_pair(pt.nodes[kv.first].se, kv.first)] = kv.second;
+    std::vector<int> nd_v;
+    for (auto& kv : pp_map_se) {
+      int nd = kv.first.second;
+      Minfo* mi = kv.second;
+      uint32_t nch = (uint32_t)pt.nodes[nd].children.size();
+      if (nch != pt.nodes[nd].eff_nchildren || nch == 1) continue;
+      if (p.no_filter || (mi->get_leq_tau(p.tau) > 1.0)) {
+        if (!pt.nodes[nd].is_leaf) mi->optimize_likelihood(llh, c);
+        mi->chisq = mi_closest->likelihood_ratio(mi->d_llh, llh);
+        c.llh_evals++;
+        if ((mi->chisq < p.chisq) && pt.nodes[nd].parent >= 0) nd_v.push_back(nd);
+      }
+    }
+    double total_lwr = 0;
+    for (int nd : nd_v) {
+      Minfo* mi = pp_map[nd];
+      mi->lwr = exp(-mi->chisq / 2);
+      total_lwr = total_lwr + mi->lwr;
+    }
+    if (p.multi) {
+      for (size_t i = 0; i < nd_v.size(); ++i) {
+        int nd = nd_v[i];
+        Minfo* mi = pp_map[nd];
+        mi->lwr = mi->lwr / total_lwr;
+        record(nd, *mi);
+        if (i > 0 && !tabular) text += ",";
+        if (tabular)
+          text += id + "\t" + tabular_fields(nd, *mi) + "\n";
+        else
+          text += "\n\t\t\t\t" + jplace_fields(nd, *mi);
+      }
+      if (!tabular) text += "]\n\t\t\t}";
+    } else {
+      if (nd_v.size() > 1) {
+        std::stable_sort(nd_v.begin(), nd_v.end(), [&](int lhs, int rhs) {
+          return (pt.nodes[lhs].card == pt.nodes[rhs].card) ? pp_map[lhs]->d_llh > pp_map[rhs]->d_llh
+                                                            : pt.nodes[lhs].card < pt.nodes[rhs].card;
+        });
+      }
+      if (nd_v.empty()) { // the reference dereferences nd_v.back() here (UB); nothing can be reported
+        if (!tabular) text += "]}";
+        return true;
+      }
+      int nd = nd_v.back();
+      Minfo* mi = pp_map[nd];
+      mi->lwr = mi->lwr / total_lwr;
+      record(nd, *mi);
+      if (tabular)
+        text += id + "\t" + tabular_fields(nd, *mi) + "\n";
+      else
+        text += jplace_fields(nd, *mi) + "]}";
+    }
+    return true;
   }
 
   // One read: IBatch::estimate_distances body (src/query.cpp:141-156) =
@@ -947,6 +1103,13 @@ struct Worker {
         }
     } else {
       c.accs += im_or.leaf_to_minfo.size() + im_rc.leaf_to_minfo.size();
+    }
+
+    if (place_mode) {
+      uint32_t np0 = (uint32_t)placements.size();
+      if (report_placement(node_to_minfo, nd_closest, mi_closest, name) && !tabular) has_previous = true;
+      ri.nrows = (uint32_t)placements.size() - np0;
+      return;
     }
 
     // report_distances (src/query.cpp:158-196), non-summarize branch.
@@ -1248,7 +1411,7 @@ int ko_dist_batch(const ko_index* ix, const char* bases, const uint64_t* offsets
 
 void ko_result_free(ko_result* r)
 {
-  free(r->rows), free(r->accs), free(r->hits), free(r->reads), free(r->text);
+  free(r->rows), free(r->accs), free(r->hits), free(r->reads), free(r->text), free(r->placements);
   memset(r, 0, sizeof(*r));
 }
 
@@ -1276,5 +1439,177 @@ uint64_t ko_conv_bp64_lr64(uint64_t x) { return conv_bp64_lr64(x); }
 uint32_t ko_murmur3_x86_32(const void* key, int len, uint32_t seed) { return murmur3_x86_32(key, len, seed); }
 uint64_t ko_name_hash(const char* name) { return name_hash(name); }
 uint64_t ko_xur64(uint64_t h) { return xur64_hash(h); }
+
+} // extern "C"
+
+namespace {
+void compute_card(Tree& t, int nd)
+{
+  TNode& n = t.nodes[nd];
+  if (n.is_leaf) {
+    n.card = 1;
+    return;
+  }
+  n.card = 0;
+  for (int c : n.children) {
+    compute_card(t, c);
+    n.card += t.nodes[c].card;
+  }
+}
+
+// Tree::stream_nwk_jplace (src/phytree.cpp:47-66): Newick with {edge} numbers, lengths at precision 5
+void nwk_jplace(const Tree& t, int nd, std::string& o)
+{
+  const TNode& n = t.nodes[nd];
+  if (!n.is_leaf) {
+    o += "(";
+    for (size_t i = 0; i < n.children.size(); ++i) {
+      nwk_jplace(t, n.children[i], o);
+      if (i + 1 < n.children.size()) o += ",";
+    }
+    o += ")";
+  }
+  o += n.name; // Node::stream_nwk_entry (src/phytree.hpp:146-153)
+  if (!std::isnan(n.blen)) {
+    char b[64];
+    snprintf(b, sizeof(b), ":%.5f", n.blen);
+    o += b;
+  }
+  o += "{" + std::to_string(n.se - 1) + "}";
+  if (nd == t.root) o += ";";
+}
+} // namespace
+
+extern "C" {
+
+int ko_index_set_placement_tree(ko_index* ix, const char* nwk_text, char* err, int errlen)
+{
+  uint32_t nn = ix->tree.nnodes;
+  ix->se_to_pnode.assign(nn + 1, -1);
+  if (!nwk_text) { // TargetIndex::ensure_backbone without -t (src/krepp.cpp:59-63)
+    if (!ix->wbackbone) {
+      set_err(err, errlen, "Given index lacks a tree and no backbone tree is provided...");
+      return -1;
+    }
+    ix->ptree = ix->tree;
+    for (uint32_t se = 1; se <= nn; ++se) {
+      int nd = ix->tree.get_node(se);
+      if (nd >= 0 && ix->tree.nodes[nd].is_leaf) ix->se_to_pnode[se] = nd;
+    }
+    for (auto& n : ix->ptree.nodes) n.eff_nchildren = (uint32_t)n.children.size(); // Node::add_children
+  } else { // Tree::map_to_qtree (src/phytree.cpp:421-450) + compute_eff_nchildren (:452-473)
+    Tree q;
+    if (!q.load(nwk_text)) {
+      set_err(err, errlen, q.err);
+      return -1;
+    }
+    std::map<std::string, uint32_t> name_to_se;
+    for (uint32_t se = 1; se <= nn; ++se) {
+      int nd = ix->tree.get_node(se);
+      if (nd >= 0 && ix->tree.nodes[nd].is_leaf) {
+        name_to_se[ix->tree.nodes[nd].name] = se;
+        ix->kind[se] = 0; // se_to_node[se] = nullptr until a query-tree leaf claims it
+      }
+    }
+    for (size_t nd = 0; nd < q.nodes.size(); ++nd) {
+      const TNode& n = q.nodes[nd];
+      if (n.is_leaf && !n.name.empty()) {
+        auto it = name_to_se.find(n.name);
+        if (it != name_to_se.end()) {
+          ix->se_to_pnode[it->second] = (int)nd;
+          ix->kind[it->second] = 1;
+        }
+      }
+    }
+    std::vector<char> covered(q.nodes.size(), 0);
+    for (uint32_t se = 1; se <= nn; ++se) {
+      int a = ix->se_to_pnode[se];
+      while (a >= 0 && !covered[a]) {
+        covered[a] = 1;
+        a = q.nodes[a].parent;
+      }
+    }
+    for (auto& n : q.nodes) n.eff_nchildren = 0;
+    for (size_t nd = 0; nd < q.nodes.size(); ++nd)
+      if (covered[nd] && q.nodes[nd].parent >= 0) q.nodes[q.nodes[nd].parent].eff_nchildren++;
+    ix->ptree = std::move(q);
+  }
+  compute_card(ix->ptree, ix->ptree.root);
+  ix->have_ptree = true;
+  return 0;
+}
+
+// QueryIndex::place_sequences (src/krepp.cpp:434-504): batch texts joined with ",\n" (jplace) or
+// concatenated (tabular); within a batch IBatch::place_sequences (src/query.cpp:198-216).
+int ko_place_batch(const ko_index* ix, const char* bases, const uint64_t* offsets, const char* const* names, uint32_t nreads,
+                   const ko_params* p, int tabular, ko_result* out)
+{
+  memset(out, 0, sizeof(*out));
+  if (!ix->have_ptree || p->hdist_th > 16) return -1;
+  const uint32_t B = 512;
+  uint32_t nbatch = (nreads + B - 1) / B;
+  std::vector<Worker*> parts(nbatch, nullptr);
+  std::vector<ko_readinfo> rinfo(nreads);
+  int nt = p->num_threads ? (int)p->num_threads : 1;
+  (void)nt;
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
+#endif
+  for (int64_t b = 0; b < (int64_t)nbatch; ++b) {
+    Worker* w = new Worker(ix, *p);
+    w->place_mode = true;
+    w->tabular = tabular != 0;
+    uint32_t r0 = (uint32_t)b * B, r1 = std::min(nreads, r0 + B);
+    for (uint32_t r = r0; r < r1; ++r) {
+      w->read_ix = r;
+      memset(&rinfo[r], 0, sizeof(ko_readinfo));
+      w->run_read(bases + offsets[r], offsets[r + 1] - offsets[r], names ? names[r] : nullptr, rinfo[r]);
+    }
+    parts[b] = w;
+  }
+  std::vector<ko_placement> pls;
+  std::string text;
+  bool has_previous = false;
+  for (Worker* w : parts) {
+    pls.insert(pls.end(), w->placements.begin(), w->placements.end());
+    if (tabular) {
+      text += w->text;
+    } else if (!w->text.empty()) {
+      if (has_previous) text += ",\n";
+      text += w->text;
+      has_previous = true;
+    }
+    add_counters(out->counters, w->c);
+    delete w;
+  }
+  out->nplacements = pls.size();
+  out->placements = dup_vec(pls);
+  out->reads = dup_vec(rinfo);
+  out->text_len = text.size();
+  out->text = (char*)malloc(text.size() + 1);
+  memcpy(out->text, text.c_str(), text.size() + 1);
+  return 0;
+}
+
+char* ko_place_frame(const ko_index* ix, int which, int tabular, const char* invocation, uint64_t total_qseq)
+{
+  std::string o, tree;
+  nwk_jplace(ix->ptree, ix->ptree.root, tree);
+  std::string inv = invocation ? invocation : "";
+  if (which == 0) {
+    if (tabular) // QueryIndex::header_preport (src/krepp.cpp:396-408)
+      o = "# software: krepp\tversion: v0.8.3\tinvocation :" + inv + "\n# " + tree + "\nSEQ_ID\tDISTAL_NODE\tEDGE_NUM\tLWR\tDIST\n";
+    else // begin_jplace (src/krepp.cpp:426-432)
+      o = "{\n\t\"version\" : 3,\n\t\"fields\" : [\"edge_num\", \"pendant_length\", \"distal_length\", \"likelihood\", "
+          "\"like_weight_ratio\", \"distance\"],\n\t\"placements\" : [\n";
+  } else if (!tabular) { // end_jplace (src/krepp.cpp:410-424)
+    o = "],\n\t\"metadata\" : {\n\t\t\"software\" : \"krepp\",\n\t\t\"version\" : \"v0.8.3\",\n\t\t\"repository\" : "
+        "\"https://github.com/bo1929/krepp\",\n\t\t\"num_queries\" : \"" + std::to_string(total_qseq) + "\",\n\t\t\"invocation\" : \"" +
+        inv + "\"\n\t},\n\t\"tree\" : \"" + tree + "\"\n}";
+  }
+  char* r = (char*)malloc(o.size() + 1);
+  memcpy(r, o.c_str(), o.size() + 1);
+  return r;
+}
 
 } // extern "C"

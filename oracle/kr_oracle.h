@@ -107,12 +107,21 @@ typedef struct ko_counters {
   uint64_t hits, pse_reads, rho_reads, accs, brent_runs, llh_evals, rows;
 } ko_counters;
 
+/* One placement of `krepp place` (PP_JPLACE_FIELDS, src/query.hpp:202-204). */
+typedef struct ko_placement {
+  uint32_t read;
+  uint32_t edge;         /* Node::get_en = se - 1 of the placement tree           */
+  double lwr, d_llh, v_llh, pendant, distal;
+} ko_placement;
+
 typedef struct ko_result {
   uint64_t nrows, naccs, nhits;
   ko_row* rows;
   ko_acc* accs;
   ko_hit* hits;
   ko_readinfo* reads;    /* nreads entries                                    */
+  ko_placement* placements; /* place mode                                       */
+  uint64_t nplacements;
   char* text;            /* report text (collect bit2)                        */
   uint64_t text_len;
   ko_counters counters;
@@ -140,6 +149,18 @@ uint32_t ko_front_end(const ko_index*, const char* seq, uint64_t len,
 int ko_dist_batch(const ko_index*, const char* bases, const uint64_t* offsets,
                   const char* const* names, uint32_t nreads, const ko_params* p, ko_result* out);
 void ko_result_free(ko_result*);
+
+/* `krepp place` (src/krepp.cpp:434-504, src/query.cpp:198-333).  ko_index_set_placement_tree:
+ * nwk == NULL uses the index's own backbone (TargetIndex::ensure_backbone, src/krepp.cpp:48-64),
+ * otherwise the index leaves are mapped onto the given tree (Tree::map_to_qtree,
+ * src/phytree.cpp:421-450).  Lineage files (-l) are not restated.  The text returned by
+ * ko_place_batch is the concatenation of the reference's per-batch streams (512-read batches)
+ * joined as QueryIndex::place_sequences joins them; ko_place_frame gives header / footer. */
+int ko_index_set_placement_tree(ko_index*, const char* nwk_text, char* err, int errlen);
+int ko_place_batch(const ko_index*, const char* bases, const uint64_t* offsets, const char* const* names,
+                   uint32_t nreads, const ko_params* p, int tabular, ko_result* out);
+/* which: 0 = text before the batches, 1 = text after them; caller frees with free() */
+char* ko_place_frame(const ko_index*, int which, int tabular, const char* invocation, uint64_t total_qseq);
 
 /* Likelihood and minimiser, callable on their own
  * (src/hdhistllh.hpp:71-89, src/query.cpp:426-433). */

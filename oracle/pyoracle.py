@@ -43,10 +43,14 @@ class KoCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in COUNTER_NAMES]
 
 
+PLACE_DT = np.dtype([("read", "<u4"), ("edge", "<u4"), ("lwr", "<f8"), ("d_llh", "<f8"), ("v_llh", "<f8"),
+                     ("pendant", "<f8"), ("distal", "<f8")])
+
+
 class KoResult(C.Structure):
     _fields_ = [("nrows", C.c_uint64), ("naccs", C.c_uint64), ("nhits", C.c_uint64), ("rows", C.c_void_p),
-                ("accs", C.c_void_p), ("hits", C.c_void_p), ("reads", C.c_void_p), ("text", C.c_void_p),
-                ("text_len", C.c_uint64), ("counters", KoCounters)]
+                ("accs", C.c_void_p), ("hits", C.c_void_p), ("reads", C.c_void_p), ("placements", C.c_void_p),
+                ("nplacements", C.c_uint64), ("text", C.c_void_p), ("text_len", C.c_uint64), ("counters", KoCounters)]
 
 
 _lib = None
@@ -77,6 +81,10 @@ def lib():
         l.ko_front_end.restype = C.c_uint32
         l.ko_dist_batch.argtypes = [vp, vp, vp, vp, C.c_uint32, C.POINTER(KoParams), C.POINTER(KoResult)]
         l.ko_result_free.argtypes = [C.POINTER(KoResult)]
+        l.ko_index_set_placement_tree.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int]
+        l.ko_place_batch.argtypes = [vp, vp, vp, vp, C.c_uint32, C.POINTER(KoParams), C.c_int, C.POINTER(KoResult)]
+        l.ko_place_frame.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_uint64]
+        l.ko_place_frame.restype = vp
         l.ko_llh.argtypes = [C.c_uint32] * 3 + [vp, C.c_double, C.c_double, C.c_double]
         l.ko_llh.restype = C.c_double
         l.ko_brent.argtypes = [C.c_uint32] * 3 + [vp, C.c_double, C.c_double, vp, vp]
@@ -189,6 +197,35 @@ class Index:
                    counters={k_: int(getattr(res.counters, k_)) for k_ in COUNTER_NAMES})
         self.l.ko_result_free(C.byref(res))
         return out
+
+    def set_placement_tree(self, nwk_text=None):
+        err = C.create_string_buffer(512)
+        rc = self.l.ko_index_set_placement_tree(self.h, nwk_text.encode() if nwk_text is not None else None, err, 512)
+        if rc:
+            raise RuntimeError("oracle: " + err.value.decode())
+
+    def place(self, bases, offsets, names=None, p=None, tabular=False):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        p = p or params(no_filter=0)
+        res = KoResult()
+        arr = (C.c_char_p * n)(*[s.encode() for s in names]) if names is not None else None
+        rc = self.l.ko_place_batch(self.h, bases.ctypes.data, offsets.ctypes.data, arr, n, C.byref(p), int(tabular), C.byref(res))
+        if rc:
+            raise RuntimeError(f"oracle ko_place_batch rc={rc}")
+        pl = (np.frombuffer(C.string_at(res.placements, res.nplacements * PLACE_DT.itemsize), dtype=PLACE_DT).copy()
+              if res.nplacements else np.zeros(0, PLACE_DT))
+        out = dict(placements=pl, text=C.string_at(res.text, res.text_len).decode() if res.text_len else "",
+                   counters={k_: int(getattr(res.counters, k_)) for k_ in COUNTER_NAMES})
+        self.l.ko_result_free(C.byref(res))
+        return out
+
+    def place_frame(self, which, tabular=False, invocation="", total=0):
+        ptr = self.l.ko_place_frame(self.h, which, int(tabular), invocation.encode(), total)
+        s = C.string_at(ptr).decode()
+        C.CDLL(None).free(C.c_void_p(ptr))
+        return s
 
     def close(self):
         if self.h:

@@ -222,7 +222,7 @@ def test_device_entry_points_fail_loudly_without_gpu(capi, toy_index_dir):
 
 def test_cli_usage_errors(capi):
     exe = os.path.join(ROOT, "krepp_amd", "lib", "krepp")
-    r = subprocess.run([exe, "place"], capture_output=True, text=True)
+    r = subprocess.run([exe, "seek"], capture_output=True, text=True)
     assert r.returncode == 1 and "[ERROR]" in r.stderr and "krepp version: v0.8.3" in r.stderr
     r = subprocess.run([exe, "dist", "-i", "/nonexistent", "-q", "/nonexistent"], capture_output=True, text=True)
     assert r.returncode == 1 and "[ERROR]" in r.stderr
