@@ -96,8 +96,8 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
 {
   if (!a.has("--query") || !a.has("--index-dir")) error_exit("dist/place require -q/--query and -i/--index-dir");
   if (a.has("--lineage-file")) error_exit("-l/--lineage-file is not implemented in this build (use -t or the index's backbone)");
-  if (a.flag.count("--summarize") && a.flag.at("--summarize"))
-    error_exit("--summarize is not implemented in this build");
+  const bool summarize = a.flag.count("--summarize") && a.flag.at("--summarize");
+  if (summarize && place) error_exit("--summarize is implemented for dist only in this build");
   kr_params p;
   kr_params_default(&p);
   if (a.has("--hdist-th")) p.hdist_th = (uint32_t)atoi(a.get("--hdist-th").c_str());
@@ -108,6 +108,7 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
   }
   if (a.flag.count("--multi")) p.multi = a.flag.at("--multi");
   if (place) p.no_filter = 0; // filter defaults to on for place (src/krepp.cpp:612-615)
+  if (summarize) p.no_filter = 0, p.multi = 1; // "Overrides --no-multi and --no-filter" (src/krepp.cpp:669-672, src/query.cpp:160-171)
   if (a.flag.count("--filter")) p.no_filter = !a.flag.at("--filter");
   if (a.has("--tau")) p.tau = (uint32_t)atoi(a.get("--tau").c_str());
   if (place && p.hdist_th < p.tau) error_exit("The threshold tau must be less than HD threshold --hdist-th!");
@@ -147,8 +148,8 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
   if (!place) fprintf(stderr, "Estimating distances between given sequences and references...\n");
   auto t0 = std::chrono::steady_clock::now();
   if (!place) { // header (src/krepp.cpp:311-319)
-    fprintf(out, "# software: krepp\tversion: " KREPP_VERSION "\tinvocation :%s\nSEQ_ID\tREFERENCE_NAME\tDIST\n",
-            invocation.c_str());
+    fprintf(out, "# software: krepp\tversion: " KREPP_VERSION "\tinvocation :%s\n%s\n", invocation.c_str(),
+            summarize ? "REFERENCE_NAME\tWEIGHTED_COUNT\tSEQUENCE_ABUNDANCE" : "SEQ_ID\tREFERENCE_NAME\tDIST");
   } else { // jplace opening or tabular header (src/krepp.cpp:440-447)
     char* t = nullptr;
     uint64_t l = 0;
@@ -170,6 +171,8 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
   bool eof = false;
   uint64_t total_batches = 0;
   std::string worker_err;
+  std::map<uint32_t, double> wcount; // --summarize: reference -> weighted read count (src/krepp.cpp:374-378)
+  double twcount = 0;
 
   auto worker = [&](int g) {
     kr_stream* st = nullptr;
@@ -197,7 +200,16 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
       int rc = kr_batch_submit(st, j->bases.data(), j->offsets.data(), (uint32_t)j->names.size(),
                                KR_BASES_HOST | (place ? KR_TAP_ACCS : 0u));
       if (!rc) rc = kr_batch_collect(st, &rv);
-      if (!rc && !place) rc = kr_format_dist(hx, &rv, nm.data(), &txt, &len);
+      if (!rc && !place && !summarize) rc = kr_format_dist(hx, &rv, nm.data(), &txt, &len);
+      if (!rc && summarize) { // each read shares one unit among the references it keeps (src/query.cpp:168-170)
+        std::lock_guard<std::mutex> lk(mu);
+        for (uint32_t r = 0; r < rv.nreads; ++r) {
+          uint32_t o = rv.read_off[r], n = rv.read_cnt[r], ns = 0;
+          for (uint32_t i = o; i < o + n; ++i) ns += rv.rec_sel[i];
+          for (uint32_t i = o; i < o + n; ++i)
+            if (rv.rec_sel[i]) wcount[rv.rec_key[i] >> 1] += 1.0 / ns, twcount += 1.0 / ns;
+        }
+      }
       if (!rc && place) {
         int prev = 0; // batches are joined by the writer (src/krepp.cpp:474-484)
         rc = kr_place_batch(hx, dix[g], ptree, &rv, j->offsets.data(), nm.data(), &p, tabular, &prev, &txt, &len, nullptr, nullptr);
@@ -206,7 +218,7 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
       if (rc) {
         worker_err = kr_last_error();
       } else {
-        j->text.assign(txt, len);
+        if (txt) j->text.assign(txt, len);
         kr_free(txt);
       }
       j->done = true;
@@ -289,6 +301,8 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
   cv_done.notify_all();
   writer.join();
   if (!worker_err.empty()) error_exit(worker_err);
+  if (summarize) // src/krepp.cpp:388-393 (ascending colour id instead of hash-map order)
+    for (auto& kv : wcount) fprintf(out, "%s\t%.5f\t%.5f\n", kr_host_index_node_name(hx, kv.first), kv.second, kv.second / twcount);
   if (place) {
     char* t = nullptr;
     uint64_t l = 0;

@@ -805,6 +805,9 @@ struct Worker {
   // place mode (IBatch::place_sequences, src/query.cpp:198-216)
   bool place_mode = false, tabular = false, has_previous = false;
   std::vector<ko_placement> placements;
+  // --summarize (src/query.cpp:160-171): reference -> weighted read count
+  bool summarize = false;
+  std::map<uint32_t, double> node_to_wcount;
 
   Worker(const ko_index* ix_, const ko_params& p_)
     : ix(ix_), p(p_)
@@ -1133,6 +1136,17 @@ struct Worker {
       }
     };
     bool dmax_set = !std::isnan(p.dist_max);
+    if (summarize) { // src/query.cpp:160-171: overrides --no-multi and --no-filter
+      std::vector<uint32_t> nd_v;
+      for (auto& kv : node_to_minfo) {
+        Minfo* mi = kv.second;
+        mi->chisq = mi_closest->likelihood_ratio(mi->d_llh, llh);
+        c.llh_evals++;
+        if (mi->chisq < p.chisq && (!dmax_set || mi->d_llh < p.dist_max)) nd_v.push_back(kv.first);
+      }
+      for (uint32_t nd : nd_v) node_to_wcount[nd] += 1.0 / nd_v.size();
+      return;
+    }
     if (node_to_minfo.empty() || (dmax_set && (mi_closest->d_llh > p.dist_max))) {
       emit(0, nullptr);
     } else if (p.multi) {
@@ -1364,8 +1378,8 @@ uint32_t ko_front_end(const ko_index* ix, const char* seq, uint64_t len, uint32_
 
 // QueryIndex::estimate_distances (src/krepp.cpp:347-394): one task per batch of
 // RBATCH_SIZE*DSEQ_LEN bases (src/rqseq.hpp:10-11,139); here batches of 512 reads.
-int ko_dist_batch(const ko_index* ix, const char* bases, const uint64_t* offsets, const char* const* names,
-                  uint32_t nreads, const ko_params* p, ko_result* out)
+static int dist_batch_impl(const ko_index* ix, const char* bases, const uint64_t* offsets, const char* const* names,
+                           uint32_t nreads, const ko_params* p, ko_result* out, bool summarize)
 {
   memset(out, 0, sizeof(*out));
   if (p->hdist_th > 16) return -1;
@@ -1380,6 +1394,7 @@ int ko_dist_batch(const ko_index* ix, const char* bases, const uint64_t* offsets
 #endif
   for (int64_t b = 0; b < (int64_t)nbatch; ++b) {
     Worker* w = new Worker(ix, *p);
+    w->summarize = summarize;
     uint32_t r0 = (uint32_t)b * B, r1 = std::min(nreads, r0 + B);
     for (uint32_t r = r0; r < r1; ++r) {
       w->read_ix = r;
@@ -1388,6 +1403,8 @@ int ko_dist_batch(const ko_index* ix, const char* bases, const uint64_t* offsets
     }
     parts[b] = w;
   }
+  std::map<uint32_t, double> wcount; // QueryIndex::estimate_distances merge (src/krepp.cpp:374-378)
+  double twcount = 0;
   std::vector<ko_row> rows;
   std::vector<ko_acc> accs;
   std::vector<ko_hit> hits;
@@ -1397,8 +1414,20 @@ int ko_dist_batch(const ko_index* ix, const char* bases, const uint64_t* offsets
     accs.insert(accs.end(), w->accs.begin(), w->accs.end());
     hits.insert(hits.end(), w->hits.begin(), w->hits.end());
     text += w->text;
+    for (auto& kv : w->node_to_wcount) {
+      twcount += kv.second;
+      wcount[kv.first] += kv.second;
+    }
     add_counters(out->counters, w->c);
     delete w;
+  }
+  if (summarize) { // src/krepp.cpp:388-393, ascending colour id instead of hash-map order
+    char b1[64], b2[64];
+    for (auto& kv : wcount) {
+      snprintf(b1, sizeof(b1), "%.5f", kv.second);
+      snprintf(b2, sizeof(b2), "%.5f", kv.second / twcount);
+      text += ix->names[kv.first] + "\t" + b1 + "\t" + b2 + "\n";
+    }
   }
   out->nrows = rows.size(), out->naccs = accs.size(), out->nhits = hits.size();
   out->rows = dup_vec(rows), out->accs = dup_vec(accs), out->hits = dup_vec(hits);
@@ -1407,6 +1436,19 @@ int ko_dist_batch(const ko_index* ix, const char* bases, const uint64_t* offsets
   out->text = (char*)malloc(text.size() + 1);
   memcpy(out->text, text.c_str(), text.size() + 1);
   return 0;
+}
+
+int ko_dist_batch(const ko_index* ix, const char* bases, const uint64_t* offsets, const char* const* names, uint32_t nreads,
+                  const ko_params* p, ko_result* out)
+{
+  return dist_batch_impl(ix, bases, offsets, names, nreads, p, out, false);
+}
+
+// `krepp dist --summarize` over the whole input given as one batch (src/krepp.cpp:374-393)
+int ko_dist_summarize(const ko_index* ix, const char* bases, const uint64_t* offsets, uint32_t nreads, const ko_params* p,
+                      ko_result* out)
+{
+  return dist_batch_impl(ix, bases, offsets, nullptr, nreads, p, out, true);
 }
 
 void ko_result_free(ko_result* r)

@@ -148,6 +148,8 @@ uint32_t ko_front_end(const ko_index*, const char* seq, uint64_t len,
 
 int ko_dist_batch(const ko_index*, const char* bases, const uint64_t* offsets,
                   const char* const* names, uint32_t nreads, const ko_params* p, ko_result* out);
+int ko_dist_summarize(const ko_index*, const char* bases, const uint64_t* offsets, uint32_t nreads, const ko_params* p,
+                      ko_result* out); /* out->text = REFERENCE_NAME\tWEIGHTED_COUNT\tSEQUENCE_ABUNDANCE rows */
 void ko_result_free(ko_result*);
 
 /* `krepp place` (src/krepp.cpp:434-504, src/query.cpp:198-333).  ko_index_set_placement_tree:

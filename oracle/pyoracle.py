@@ -81,6 +81,7 @@ def lib():
         l.ko_front_end.restype = C.c_uint32
         l.ko_dist_batch.argtypes = [vp, vp, vp, vp, C.c_uint32, C.POINTER(KoParams), C.POINTER(KoResult)]
         l.ko_result_free.argtypes = [C.POINTER(KoResult)]
+        l.ko_dist_summarize.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(KoParams), C.POINTER(KoResult)]
         l.ko_index_set_placement_tree.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int]
         l.ko_place_batch.argtypes = [vp, vp, vp, vp, C.c_uint32, C.POINTER(KoParams), C.c_int, C.POINTER(KoResult)]
         l.ko_place_frame.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_uint64]
@@ -197,6 +198,17 @@ class Index:
                    counters={k_: int(getattr(res.counters, k_)) for k_ in COUNTER_NAMES})
         self.l.ko_result_free(C.byref(res))
         return out
+
+    def summarize(self, bases, offsets, p=None):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        p = p or params()
+        res = KoResult()
+        rc = self.l.ko_dist_summarize(self.h, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, C.byref(p), C.byref(res))
+        assert rc == 0
+        txt = C.string_at(res.text, res.text_len).decode() if res.text_len else ""
+        self.l.ko_result_free(C.byref(res))
+        return txt
 
     def set_placement_tree(self, nwk_text=None):
         err = C.create_string_buffer(512)

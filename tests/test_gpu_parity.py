@@ -343,3 +343,24 @@ def test_cli_dist_end_to_end(capi, po, toy_index_dir, toy_reads, tmp_path):
     r = subprocess.run([exe, "--num-threads", "2", "dist", "-i", toy_index_dir, "-q", str(gz), "-o", str(out)], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout == ""
     assert out.read_text().split("\n", 2)[2] == ox.dist(bases, offs, names, po.params(collect=4))["text"]
+
+
+def test_cli_dist_summarize(po, toy_index_dir, toy_reads):
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "krepp_amd", "lib", "krepp")
+    fq = os.path.join(GOLDEN, "toy_reads.fq")
+    names, bases, offs = toy_reads
+    r = subprocess.run([exe, "dist", "-i", toy_index_dir, "-q", fq, "--summarize"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.split("\n")
+    assert lines[1] == "REFERENCE_NAME\tWEIGHTED_COUNT\tSEQUENCE_ABUNDANCE"
+    want = po.Index(toy_index_dir).summarize(bases, offs, po.params())
+    got = "\n".join(lines[2:])
+    # weighted counts are sums of 1/n in a different order: compare numerically, names exactly
+    gw = [l.split("\t") for l in got.strip().split("\n")]
+    ww = [l.split("\t") for l in want.strip().split("\n")]
+    assert [g[0] for g in gw] == [w[0] for w in ww] and len(gw) >= 20
+    for g, w in zip(gw, ww):
+        assert abs(float(g[1]) - float(w[1])) <= 2e-5 and abs(float(g[2]) - float(w[2])) <= 2e-5
+    assert abs(sum(float(g[2]) for g in gw) - 1.0) < 1e-3
