@@ -183,7 +183,9 @@ typedef struct kr_result_view {
   const double* rec_d;        /* [nrecs]  d_llh                                          */
   const double* rec_v;        /* [nrecs]  v_llh                                          */
   const double* rec_chisq;    /* [nrecs]  chi-square vs the closest (filter mode), else NaN */
-  const uint32_t* rec_hist;   /* [nrecs * (hdist_th+1)] with KR_TAP_ACCS, else NULL      */
+  const uint32_t* rec_hist;   /* with KR_TAP_ACCS, else NULL: hist[x] of record i at      */
+                              /* rec_hist[x * rec_hist_stride + i], x = 0..hdist_th       */
+  uint64_t rec_hist_stride;
   uint64_t nrows;             /* number of rec_sel == 1                                  */
 } kr_result_view;
 

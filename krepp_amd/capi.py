@@ -52,7 +52,7 @@ class KrResultView(C.Structure):
     _fields_ = [("nreads", C.c_uint32), ("nrecs", C.c_uint32),
                 ("read_off", u32p), ("read_cnt", u32p), ("read_onmers", u32p), ("read_na", u8p),
                 ("rec_key", u32p), ("rec_sel", u8p), ("rec_d", f64p), ("rec_v", f64p),
-                ("rec_chisq", f64p), ("rec_hist", u32p), ("nrows", C.c_uint64)]
+                ("rec_chisq", f64p), ("rec_hist", u32p), ("rec_hist_stride", C.c_uint64), ("nrows", C.c_uint64)]
 
 
 class KrHit(C.Structure):
@@ -336,8 +336,8 @@ class Result:
         self.rec_d = _np(rv.rec_d, c, np.float64)[keep]
         self.rec_v = _np(rv.rec_v, c, np.float64)[keep]
         self.rec_chisq = _np(rv.rec_chisq, c, np.float64)[keep]
-        self.rec_hist = (_np(rv.rec_hist, c * np_planes, np.uint32).reshape(-1, np_planes)[keep]
-                         if copy_hist and rv.rec_hist else None)
+        self.rec_hist = (_np(rv.rec_hist, c * np_planes, np.uint32).reshape(np_planes, -1).T[keep]
+                         if copy_hist and rv.rec_hist and c else (np.zeros((0, np_planes), np.uint32) if copy_hist else None))
         # read index of every record, and offsets into the compacted arrays
         rr = np.zeros(c, np.uint32)
         for r in np.nonzero(self.read_cnt)[0]:

@@ -105,7 +105,7 @@ struct BatchOut {
   uint8_t* rd_na;
   uint32_t* rec_read;
   uint32_t* rec_key;
-  uint32_t* rec_hist;    // [rec_cap * np]
+  uint32_t* rec_hist;    // [np][rec_cap]: hist[x] of record i at x * rec_cap + i (coalesced across records)
   double* rec_d;
   double* rec_v;
   double* rec_chisq;
@@ -828,7 +828,7 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
         out.rec_read[ri] = read;
         out.rec_key[ri] = (ix.leaf_se[rs >> 1] << 1) | (rs & 1u);
         for (uint32_t x = 0; x < A.np; ++x)
-          out.rec_hist[(uint64_t)ri * A.np + x] = (hist[o * hw + (x >> 2)] >> (8u * (x & 3u))) & 255u;
+          out.rec_hist[(uint64_t)x * out.rec_cap + ri] = (hist[o * hw + (x >> 2)] >> (8u * (x & 3u))) & 255u;
       }
       run += __popcll(okm);
     }
@@ -966,7 +966,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
       uint32_t ri = rbase + rank;
       out.rec_read[ri] = read;
       out.rec_key[ri] = (ix.leaf_se[(key >> 1) - 1u] << 1) | (key & 1u);
-      for (uint32_t x = 0; x < A.np; ++x) out.rec_hist[(uint64_t)ri * A.np + x] = A.counts[lane * A.np + x];
+      for (uint32_t x = 0; x < A.np; ++x) out.rec_hist[(uint64_t)x * out.rec_cap + ri] = A.counts[lane * A.np + x];
     }
     if (key) { // leave the slot empty for the next read
       A.keys[lane] = 0;
@@ -1029,7 +1029,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
       out.rec_read[ri] = read;
       out.rec_key[ri] = (ix.leaf_se[slot2 >> 1] << 1) | (slot2 & 1u);
       for (uint32_t x = 0; x < A.np; ++x)
-        out.rec_hist[(uint64_t)ri * A.np + x] = gload(&A.g_counts[(uint64_t)slot2 * A.np + x]);
+        out.rec_hist[(uint64_t)x * out.rec_cap + ri] = gload(&A.g_counts[(uint64_t)slot2 * A.np + x]);
     }
     if (t < n2)
       for (uint32_t x = 0; x < A.np; ++x) gstore(&A.g_counts[(uint64_t)slot2 * A.np + x], 0);
@@ -1243,20 +1243,22 @@ __device__ __forceinline__ void brent_min(const LlhConst& C, const LlhTables& T,
 }
 
 template <int NPT>
-__device__ __forceinline__ void load_problem(const LlhConst& C, const uint32_t* hist, uint32_t onmers, double rho,
-                                             LlhProblem& p)
-{
+__device__ __forceinline__ void load_problem(const LlhConst& C, const uint32_t* hist, uint64_t stride, uint32_t onmers,
+                                             double rho, LlhProblem& p)
+{ // hist[x] of this record at hist[x * stride]
   uint32_t mc = 0;
   if (NPT > 0) {
 #pragma unroll
     for (int x = 0; x < NPT; ++x) {
-      p.mc[x] = (double)hist[x];
-      mc += hist[x];
+      uint32_t hv = hist[(uint64_t)x * stride];
+      p.mc[x] = (double)hv;
+      mc += hv;
     }
   } else {
     for (uint32_t x = 0; x <= C.th; ++x) {
-      p.mc[x] = (double)hist[x];
-      mc += hist[x];
+      uint32_t hv = hist[(uint64_t)x * stride];
+      p.mc[x] = (double)hv;
+      mc += hv;
     }
   }
   p.uc = (double)onmers - (double)mc; // mismatch_count = onmers - match_count (src/query.cpp:104)
@@ -1272,7 +1274,7 @@ __device__ __forceinline__ void llh_records(const LlhConst& C, const LlhTables& 
     if (key == 0) continue; // hole at the end of a wave's record chunk
     uint32_t read = out.rec_read[i];
     LlhProblem p;
-    load_problem<NPT>(C, out.rec_hist + (uint64_t)i * (C.th + 1), out.rd_onmers[read], ix.libs[0].rho[key >> 1], p);
+    load_problem<NPT>(C, out.rec_hist + i, out.rec_cap, out.rd_onmers[read], ix.libs[0].rho[key >> 1], p);
     double d, v;
     brent_min<NPT>(C, T, p, d, v);
     out.rec_d[i] = d;
@@ -1317,8 +1319,7 @@ __global__ __launch_bounds__(256) void kr_select_kernel(LlhConst C, DevIndex ix,
     LlhProblem pc;
     double vcl = 0;
     if (cl >= 0 && !P.no_filter) {
-      load_problem<0>(C, out.rec_hist + (uint64_t)cl * (C.th + 1), out.rd_onmers[r], ix.libs[0].rho[out.rec_key[cl] >> 1],
-                      pc);
+      load_problem<0>(C, out.rec_hist + cl, out.rec_cap, out.rd_onmers[r], ix.libs[0].rho[out.rec_key[cl] >> 1], pc);
       vcl = out.rec_v[cl];
     }
     for (uint32_t i = o; i < o + n; ++i) {
@@ -1333,8 +1334,8 @@ __global__ __launch_bounds__(256) void kr_select_kernel(LlhConst C, DevIndex ix,
         double d_or = out.rec_d[io], d_rc = out.rec_d[ir];
         uint32_t m_or = 0, m_rc = 0;
         for (uint32_t x = 0; x <= C.th; ++x) {
-          m_or += out.rec_hist[(uint64_t)io * (C.th + 1) + x];
-          m_rc += out.rec_hist[(uint64_t)ir * (C.th + 1) + x];
+          m_or += out.rec_hist[(uint64_t)x * out.rec_cap + io];
+          m_rc += out.rec_hist[(uint64_t)x * out.rec_cap + ir];
         }
         bool take_or = (d_rc > d_or) || ((d_rc == d_or) && (m_rc < m_or)); // src/query.cpp:129-133
         // the closest overrides (src/query.cpp:136-138)
@@ -1405,7 +1406,7 @@ __global__ void kr_brent_kernel(LlhConst C, uint32_t n, const uint32_t* hist, co
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   LlhProblem p;
-  load_problem<NPT>(C, hist + (uint64_t)i * (C.th + 1), onmers[i], rho[i], p);
+  load_problem<NPT>(C, hist + (uint64_t)i * (C.th + 1), 1, onmers[i], rho[i], p);
   brent_min<NPT>(C, T, p, d_out[i], v_out[i]);
 }
 
@@ -2060,10 +2061,12 @@ static void fill_view(kr_stream* s, kr_result_view* v, bool device)
     v->read_off = s->out.rd_off, v->read_cnt = s->out.rd_cnt, v->read_onmers = s->out.rd_onmers, v->read_na = s->out.rd_na;
     v->rec_key = s->out.rec_key, v->rec_sel = s->out.rec_sel, v->rec_d = s->out.rec_d, v->rec_v = s->out.rec_v;
     v->rec_chisq = s->out.rec_chisq, v->rec_hist = s->out.rec_hist;
+    v->rec_hist_stride = s->rec_cap;
   } else {
     v->read_off = s->h_rd_off, v->read_cnt = s->h_rd_cnt, v->read_onmers = s->h_rd_onmers, v->read_na = s->h_rd_na;
     v->rec_key = s->h_rec_key, v->rec_sel = s->h_rec_sel, v->rec_d = s->h_rec_d, v->rec_v = s->h_rec_v;
     v->rec_chisq = s->h_rec_chisq, v->rec_hist = (s->flags & KR_TAP_ACCS) ? s->h_rec_hist : nullptr;
+    v->rec_hist_stride = s->nrecs;
   }
 }
 
@@ -2102,7 +2105,8 @@ int kr_batch_collect(kr_stream* s, kr_result_view* v)
     HIP_TRY(hipMemcpyAsync(s->h_rec_v, s->out.rec_v, nc * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(s->h_rec_chisq, s->out.rec_chisq, nc * 8, hipMemcpyDeviceToHost, st));
     if (s->flags & KR_TAP_ACCS)
-      HIP_TRY(hipMemcpyAsync(s->h_rec_hist, s->out.rec_hist, nc * s->dp.np * 4, hipMemcpyDeviceToHost, st));
+      for (uint32_t x = 0; x < s->dp.np; ++x)
+        HIP_TRY(hipMemcpyAsync(s->h_rec_hist + (uint64_t)x * nc, s->out.rec_hist + (uint64_t)x * s->rec_cap, nc * 4, hipMemcpyDeviceToHost, st));
   }
   if ((s->flags & KR_TAP_HITS) && s->nhits)
     HIP_TRY(hipMemcpyAsync(s->h_hits, s->out.hits, s->nhits * sizeof(kr_hit), hipMemcpyDeviceToHost, st));

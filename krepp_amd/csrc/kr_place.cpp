@@ -221,7 +221,7 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
       a.leaf = true;
       a.hist.resize(np);
       double mc = 0;
-      for (uint32_t x = 0; x < np; ++x) a.hist[x] = rv->rec_hist[(uint64_t)i * np + x], mc += a.hist[x];
+      for (uint32_t x = 0; x < np; ++x) a.hist[x] = rv->rec_hist[(uint64_t)x * rv->rec_hist_stride + i], mc += a.hist[x];
       a.match = mc;
       a.mismatch = (double)rv->read_onmers[r] - mc; // src/query.cpp:104
       a.nmers = enmers;                              // IMers::enmers (src/query.cpp:335-350)
