@@ -16,10 +16,10 @@
 //                        [src/query.cpp:101-106,119] and record emission.
 //   kr_probe_overflow_kernel  same code, accumulator table in global memory, for reads
 //                        whose leaf set does not fit the LDS table.
-//   kr_llh_kernel        one lane per (read, strand, leaf) record: Brent minimisation of
-//                        HDistHistLLH in fp64 [src/hdhistllh.hpp:51-96,
+//   kr_llh_kernel        one lane per (read, strand, leaf) record, lanes refilled as their
+//                        minimisations converge: Brent minimisation of HDistHistLLH in fp64 [src/hdhistllh.hpp:51-96,
 //                        src/query.cpp:426-433, boost::math::tools::brent_find_minima].
-//   kr_select_kernel     one lane per read: strand merge, closest reference, --filter /
+//   kr_select_kernel     32 lanes per read, one record per lane: strand merge, closest reference, --filter /
 //                        --dist-max / --no-multi selection [src/query.cpp:96-139,158-196].
 //
 // Exactness: Minfo::update_match counts, per read position, only the smallest Hamming
@@ -58,6 +58,7 @@ constexpr int kStackCap = 256;    // colour work stack (items of 8 B)
 constexpr int kLdsSlots = 64;     // level-1 (LDS) accumulator slots per wave: lane t owns slot t in the epilogue
 constexpr int kLdsProbeMax = 8;   // bounded probe sequence of the level-1 table
 constexpr int kMaxPlanes = KR_MAX_HDIST_TH + 1;
+constexpr int kHistWords = (kMaxPlanes + 3) / 4; // packed 8-bit histogram counters
 
 struct DevLib {
   const uint64_t* bkt;  // [nrows]  (start << 24) | len
@@ -91,7 +92,7 @@ struct LlhConst {
 struct DevParams {
   uint32_t th, np;       // np = th + 1 planes
   uint32_t multi, no_filter, dmax_set;
-  uint32_t dbg; // KR_DEBUG_SKIP (timing experiments only): 1 drop hits, 2 drop expansion, 4 skip scan
+  uint32_t dbg; // KR_DEBUG_SKIP (timing experiments only): 1 drop hits, 2 drop expansion, 4 skip scan, 8 no event mode, 16 drop events
   double chisq, dist_max;
 };
 
@@ -118,7 +119,8 @@ struct BatchOut {
   uint32_t* g_counts; // [nwaves][nslots2][np]
   uint32_t* g_list;   // [nwaves][nslots2]
   uint32_t nslots2;   // 2 * nleaves
-  uint32_t g_list_words; // per wave: max(nslots2, event capacity)
+  uint32_t g_list_words; // per wave: max(nslots2, ev_spill + tab_spill * (hist words + 1))
+  uint32_t ev_spill, tab_spill, kt_spill; // event-mode spill capacities per wave (events, table entries, keys)
   uint32_t bm_words;  // ceil(nslots2 / 32)
 };
 
@@ -141,6 +143,7 @@ __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 #define KR_LDS __attribute__((address_space(3)))
 typedef KR_LDS uint32_t lds_u32;
 typedef KR_LDS uint64_t lds_u64;
+typedef KR_LDS uint16_t lds_u16;
 __device__ __forceinline__ uint32_t lds_cas(lds_u32* p, uint32_t expected, uint32_t desired)
 {
   __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -263,7 +266,8 @@ struct Acc {
   lds_u32* planes;  // [kLdsSlots * np * 4]
   lds_u32* counts;  // [kLdsSlots * np]
   // level 2
-  lds_u32* bitmap;   // LDS [bm_words]
+  lds_u32* bitmap;   // LDS [bm_words] (bm_words even, 8-byte aligned)
+  lds_u16* pre;      // LDS [bm_words / 2]: key ordinal prefix per 64-bit bitmap block (event mode)
   uint32_t* g_planes; // global [nslots2 * np * 4]
   uint32_t* g_counts; // global [nslots2 * np]
   uint32_t* g_list;   // global [nslots2]
@@ -297,6 +301,10 @@ struct WaveState {
   bool ev_full;     // wave-uniform: the event buffer overflowed
   uint32_t nev;     // events buffered (wave-uniform)
   uint32_t ev_cap;  // power of two
+  uint32_t ev_words; // words of the region the events and the epilogue's batch arrays share (level-1 planes + counts)
+  bool dirty;       // wave-uniform: event mode left data in the level-1 table regions (zeroed on demand)
+  uint32_t* gev;    // global spill: events beyond ev_cap, then table entries beyond the LDS table
+  uint32_t gev_cap, gtab_cap, gkt_cap; // spill capacities (events / table entries / keys)
   lds_u32* ev;      // aliases the level-1 planes + counts region
 };
 
@@ -351,8 +359,14 @@ __device__ __forceinline__ void add_leaf_events(const Acc& A, WaveState& ws, boo
   if (m == 0) return;
   if (ws.evmode) {
     const uint32_t c = __popcll(m);
-    if (ws.nev + c <= ws.ev_cap) {
-      if (f) ws.ev[ws.nev + __popcll(m & ((1ull << lane_id()) - 1ull))] = ev;
+    if (ws.nev + c <= ws.ev_cap + ws.gev_cap) {
+      if (f) {
+        const uint32_t i = ws.nev + __popcll(m & ((1ull << lane_id()) - 1ull));
+        if (i < ws.ev_cap)
+          ws.ev[i] = ev;
+        else
+          gstore(&ws.gev[i - ws.ev_cap], ev); // long event lists continue in (L2-resident) global scratch
+      }
       ws.nev += c;
     } else {
       ws.ev_full = true; // the read is redone with the plane tables (rare)
@@ -479,33 +493,34 @@ __device__ __forceinline__ Cand fetch_group(const DevIndex& ix, const SegBits& s
   return c;
 }
 
-// 4 entries of one 16-byte chunk against the query code: 4-bit hit mask, 4 x 8-bit hd
-__device__ __forceinline__ void chunk_hits(uint4 v, uint64_t e0, uint64_t st, uint32_t ln, uint32_t q, uint32_t th,
-                                           uint32_t& mask, uint32_t& hds)
+// 4 entries of one 16-byte chunk against the query code.  `lo`/`hi` bound the entries of the chunk
+// that belong to the bucket (0..4).  Returns the 4-bit hit mask; hds = 4 x 8-bit Hamming distances.
+__device__ __forceinline__ uint32_t chunk_hits(uint4 v, int lo, int hi, uint32_t q, uint32_t th, uint32_t& hds)
 {
   uint32_t h0 = hd_lr32(v.x, q), h1 = hd_lr32(v.y, q), h2 = hd_lr32(v.z, q), h3 = hd_lr32(v.w, q);
-  uint64_t en = st + ln;
-  bool b0 = e0 >= st && e0 < en && h0 <= th;
-  bool b1 = e0 + 1 >= st && e0 + 1 < en && h1 <= th;
-  bool b2 = e0 + 2 >= st && e0 + 2 < en && h2 <= th;
-  bool b3 = e0 + 3 >= st && e0 + 3 < en && h3 <= th;
-  mask = (b0 ? 1u : 0u) | (b1 ? 2u : 0u) | (b2 ? 4u : 0u) | (b3 ? 8u : 0u);
   hds = h0 | (h1 << 8) | (h2 << 16) | (h3 << 24);
+  uint32_t m = (h0 <= th ? 1u : 0u) | (h1 <= th ? 2u : 0u) | (h2 <= th ? 4u : 0u) | (h3 <= th ? 8u : 0u);
+  lo = max(lo, 0), hi = min(hi, 4);
+  uint32_t in = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+  return m & in;
 }
 
 // Scan the listed buckets: G = 2^LOG_G consecutive lanes share one probe and read consecutive
 // aligned 16-byte chunks of its bucket (G*16 contiguous bytes per step); 64/G probes per pass;
-// two chunks per lane per pass, and the loads of the NEXT pass are issued before the current
-// pass is examined (software pipeline: four 16-byte loads in flight per lane).  No search, no
-// prefix sums: the probe of a lane is fixed by its lane id.
+// CPL chunks per lane per pass, and the loads of the NEXT pass are issued before the current
+// pass is examined (software pipeline: 2*CPL 16-byte loads in flight per lane).  No search, no
+// prefix sums: the probe of a lane is fixed by its lane id.  A pass covers G*CPL*4 entries of each
+// bucket; longer buckets take extra (unpipelined) rounds.
+template <int CPL>
 struct ScanStep {
-  uint64_t st, eA;
-  uint32_t ln, q, tg, nch;
-  uint4 vA, vB;
+  uint64_t e_al;  // aligned entry index of the bucket's first chunk
+  int rel0, tot;  // bucket = entries [rel0, tot) relative to e_al
+  uint32_t q, tg, nch;
+  uint4 v[CPL];
 };
 
-template <int LOG_G, bool SL>
-__device__ __forceinline__ void scan_issue(const DevIndex& ix, const ProbeList& pl, uint32_t nact, uint32_t p0, ScanStep& S)
+template <int LOG_G, int CPL, bool SL>
+__device__ __forceinline__ void scan_issue(const DevIndex& ix, const ProbeList& pl, uint32_t nact, uint32_t p0, ScanStep<CPL>& S)
 {
   constexpr uint32_t G = 1u << LOG_G;
   const uint32_t lane = lane_id();
@@ -514,36 +529,45 @@ __device__ __forceinline__ void scan_issue(const DevIndex& ix, const ProbeList& 
   const uint64_t b = on ? pl.bkt[pi] : 0ull;
   S.q = on ? pl.q[pi] : 0u;
   S.tg = on ? pl.tag[pi] : 0u;
-  S.st = b >> 24;
-  S.ln = (uint32_t)(b & 0xFFFFFFu);
-  S.nch = on ? (uint32_t)(((S.st & 3u) + S.ln + 3u) >> 2) : 0u;
-  S.eA = (S.st & ~3ull) + 4ull * sub;
-  S.vA = make_uint4(0, 0, 0, 0);
-  S.vB = S.vA;
-  const uint32_t* enc = get_lib<SL>(ix, tag_lib(S.tg)).enc;
-  if (sub < S.nch) S.vA = *reinterpret_cast<const uint4*>(enc + S.eA);
-  if (sub + G < S.nch) S.vB = *reinterpret_cast<const uint4*>(enc + S.eA + 4ull * G);
+  const uint64_t st = b >> 24;
+  const uint32_t ln = (uint32_t)(b & 0xFFFFFFu);
+  S.e_al = st & ~3ull;
+  S.rel0 = (int)(st & 3u);
+  S.tot = S.rel0 + (int)ln;
+  S.nch = on ? (uint32_t)(S.tot + 3) >> 2 : 0u;
+  const uint32_t* enc = get_lib<SL>(ix, tag_lib(S.tg)).enc + S.e_al;
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const uint32_t c = sub + (uint32_t)j * G;
+    S.v[j] = make_uint4(0, 0, 0, 0);
+    if (c < S.nch) S.v[j] = *reinterpret_cast<const uint4*>(enc + 4u * c);
+  }
 }
 
-// push the hits of two chunks (A at entry eA, B at entry eB) as unresolved work items
-template <bool SL, bool TAP>
+struct Hds3 { uint32_t a, b, c; }; // per-chunk Hamming distances (4 x 8 bit) of up to 3 chunks, kept in registers
+
+// push hits as unresolved work items: pend = hit mask (4 bits per chunk), hds[j] the chunk's distances,
+// chunk j of this lane starts at entry e_al + 4 * (c0 + j*G)
+template <int LOG_G, int CPL, bool SL, bool TAP>
 __device__ __forceinline__ void push_hits(const DevIndex& ix, const BatchOut& out, const Acc& A, WaveState& ws, uint32_t tg,
-                                          uint64_t eA, uint64_t eB, uint32_t mA, uint32_t hA, uint32_t mB, uint32_t hB,
-                                          uint32_t& filt0, uint32_t& filt1, uint32_t P_dbg)
+                                          uint64_t e_al, uint32_t c0, uint32_t pend, Hds3 hds, uint32_t& filt0,
+                                          uint32_t& filt1)
 {
+  constexpr uint32_t G = 1u << LOG_G;
   const uint32_t lane = lane_id();
   const uint64_t lt = (1ull << lane) - 1ull;
-  uint32_t pend = mA | (mB << 4);
-  if (P_dbg & 1u) pend = 0;
   while (__ballot(pend != 0) != 0) {
     if (ws.top > (uint32_t)(kStackCap - 64)) expand_all<SL, TAP>(ix, out, A, ws);
     const bool has = pend != 0;
     const uint32_t bit = has ? (uint32_t)__ffs((int)pend) - 1u : 0u;
-    const uint32_t e = bit & 3u;
+    const uint32_t e = bit & 3u, j = bit >> 2;
     const uint64_t hm = __ballot(has);
     if (has) {
-      const uint32_t hd = (((bit >> 2) ? hB : hA) >> (8 * e)) & 31u;
-      const uint64_t idx = ((bit >> 2) ? eB : eA) + e;
+      uint32_t hw = hds.a;
+      if (CPL > 1) hw = j == 1u ? hds.b : hw;
+      if (CPL > 2) hw = j == 2u ? hds.c : hw;
+      const uint32_t hd = (hw >> (8 * e)) & 31u;
+      const uint64_t idx = e_al + 4ull * (c0 + j * G) + e;
       if (tag_strand(tg))
         filt1 = min(filt1, hd);
       else
@@ -557,7 +581,7 @@ __device__ __forceinline__ void push_hits(const DevIndex& ix, const BatchOut& ou
   }
 }
 
-template <int LOG_G, bool SL, bool TAP>
+template <int LOG_G, int CPL, bool SL, bool TAP>
 __device__ __forceinline__ void scan_list(const DevIndex& ix, const DevParams& P, const BatchOut& out, const Acc& A,
                                           WaveState& ws, const ProbeList& pl, uint32_t nact, uint32_t& filt0,
                                           uint32_t& filt1)
@@ -565,32 +589,51 @@ __device__ __forceinline__ void scan_list(const DevIndex& ix, const DevParams& P
   constexpr uint32_t G = 1u << LOG_G, PPS = 64u >> LOG_G;
   const uint32_t sub = lane_id() & (G - 1u);
   if (nact == 0) return;
-  ScanStep cur, nxt;
-  scan_issue<LOG_G, SL>(ix, pl, nact, 0, cur);
+  ScanStep<CPL> cur, nxt;
+  scan_issue<LOG_G, CPL, SL>(ix, pl, nact, 0, cur);
   for (uint32_t p0 = 0; p0 < nact; p0 += PPS) {
     nxt = cur;
-    if (p0 + PPS < nact) scan_issue<LOG_G, SL>(ix, pl, nact, p0 + PPS, nxt);
-    // ---- first two chunks of every probe of this pass (already loaded)
+    if (p0 + PPS < nact) scan_issue<LOG_G, CPL, SL>(ix, pl, nact, p0 + PPS, nxt);
+    // ---- first CPL chunks per lane of every probe of this pass (already loaded)
     {
-      uint32_t mA = 0, hA = 0, mB = 0, hB = 0;
-      const uint64_t eB = cur.eA + 4ull * G;
-      if (sub < cur.nch) chunk_hits(cur.vA, cur.eA, cur.st, cur.ln, cur.q, P.th, mA, hA);
-      if (sub + G < cur.nch) chunk_hits(cur.vB, eB, cur.st, cur.ln, cur.q, P.th, mB, hB);
-      push_hits<SL, TAP>(ix, out, A, ws, cur.tg, cur.eA, eB, mA, hA, mB, hB, filt0, filt1, P.dbg);
+      uint32_t pend = 0;
+      Hds3 hds{0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int c = (int)(sub + (uint32_t)j * G);
+        uint32_t h = 0;
+        if ((uint32_t)c < cur.nch) pend |= chunk_hits(cur.v[j], cur.rel0 - 4 * c, cur.tot - 4 * c, cur.q, P.th, h) << (4 * j);
+        if (j == 0) hds.a = h;
+        if (j == 1) hds.b = h;
+        if (j == 2) hds.c = h;
+      }
+      if (P.dbg & 1u) pend = 0;
+      push_hits<LOG_G, CPL, SL, TAP>(ix, out, A, ws, cur.tg, cur.e_al, sub, pend, hds, filt0, filt1);
     }
-    // ---- buckets longer than 2*G chunks: the rest, two chunks per lane at a time
-    if (__ballot(cur.nch > 2u * G) != 0) {
-      const uint32_t* enc = get_lib<SL>(ix, tag_lib(cur.tg)).enc;
-      for (uint32_t c = sub + 2u * G; __ballot(c < cur.nch) != 0; c += 2u * G) {
-        const bool onA = c < cur.nch, onB = c + G < cur.nch;
-        const uint64_t eA = (cur.st & ~3ull) + 4ull * c, eB = eA + 4ull * G;
-        uint4 vA = make_uint4(0, 0, 0, 0), vB = vA;
-        if (onA) vA = *reinterpret_cast<const uint4*>(enc + eA);
-        if (onB) vB = *reinterpret_cast<const uint4*>(enc + eB);
-        uint32_t mA = 0, hA = 0, mB = 0, hB = 0;
-        if (onA) chunk_hits(vA, eA, cur.st, cur.ln, cur.q, P.th, mA, hA);
-        if (onB) chunk_hits(vB, eB, cur.st, cur.ln, cur.q, P.th, mB, hB);
-        push_hits<SL, TAP>(ix, out, A, ws, cur.tg, eA, eB, mA, hA, mB, hB, filt0, filt1, P.dbg);
+    // ---- buckets longer than G*CPL chunks: the rest, CPL chunks per lane at a time
+    if (__ballot(cur.nch > G * CPL) != 0) {
+      const uint32_t* enc = get_lib<SL>(ix, tag_lib(cur.tg)).enc + cur.e_al;
+      for (uint32_t c0 = sub + G * CPL; __ballot(c0 < cur.nch) != 0; c0 += G * CPL) {
+        uint4 v[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          const uint32_t c = c0 + (uint32_t)j * G;
+          v[j] = make_uint4(0, 0, 0, 0);
+          if (c < cur.nch) v[j] = *reinterpret_cast<const uint4*>(enc + 4u * c);
+        }
+        uint32_t pend = 0;
+        Hds3 hds{0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          const int c = (int)(c0 + (uint32_t)j * G);
+          uint32_t h = 0;
+          if ((uint32_t)c < cur.nch) pend |= chunk_hits(v[j], cur.rel0 - 4 * c, cur.tot - 4 * c, cur.q, P.th, h) << (4 * j);
+          if (j == 0) hds.a = h;
+          if (j == 1) hds.b = h;
+          if (j == 2) hds.c = h;
+        }
+        if (P.dbg & 1u) pend = 0;
+        push_hits<LOG_G, CPL, SL, TAP>(ix, out, A, ws, cur.tg, cur.e_al, c0, pend, hds, filt0, filt1);
       }
     }
     cur = nxt;
@@ -673,6 +716,7 @@ __device__ __forceinline__ uint32_t hmin_l2(const Acc& A, uint32_t slot2)
 // which is the read rate of the small-index configuration).  Unused slots at the end of a chunk stay
 // zero (key 0 = hole; the record arrays are zeroed per batch).
 constexpr uint32_t kRecChunk = 256;
+constexpr uint32_t kEvSpill = 15360; // events of one read beyond the LDS buffer (60 KiB of global scratch per wave)
 __device__ __forceinline__ uint32_t alloc_records(const BatchOut& out, WaveState& ws, uint32_t n)
 {
   if (ws.rec_next + n > ws.rec_end) {
@@ -693,157 +737,224 @@ __device__ __forceinline__ uint32_t alloc_records(const BatchOut& out, WaveState
 }
 
 // ---------------------------------------------------------------------------
-// Event mode epilogue: sort the events, keep the first event of every (leaf, strand, pos) group
-// (= the smallest hd at that position: the rule of Minfo::update_match, src/query.hpp:153-176),
-// histogram per (leaf, strand), apply the hdist_filt test, emit records in key order.
-// All in LDS; the histogram table lives in the (now idle) stack + probe-list regions.
-// Returns false if the read has more distinct keys than the table holds (caller falls back).
+// Event mode epilogue.  No sort:
+//  1. the keys (2 * leaf rank + strand) of the read's events are marked in the LDS bitmap; a popcount
+//     prefix over the bitmap gives every key its ORDINAL among the read's keys (ascending key =
+//     ascending colour id, strands adjacent);
+//  2. every event is rewritten in place as  ordinal << 12 | pos << 5 | hd  and its key stored in
+//     keytab[ordinal];
+//  3. the per-position minimum of Minfo::update_match (src/query.hpp:153-176) is taken by visiting the
+//     events in ascending hd LEVELS: an event sets bit `pos` of its key's 128-bit position map with a
+//     returning LDS atomic OR, and only the event that finds the bit clear increments the key's
+//     histogram counter of that level (8-bit counters, four per word: a segment has <= 128 positions);
+//  4. keys that pass `hdist_min <= 2*hdist_filt+1` (src/query.cpp:101-106,119) are appended to a
+//     compact table (counters + key) and written out at the end.
+// Position maps and counters hold KB keys at a time (4 + hw words per key, all of the idle LDS behind
+// the events: a single batch for all but the largest reads).  LDS use: [tab ... keytab] in the idle
+// stack / probe-list / level-1 key region, [events | batch arrays] in the level-1 plane region.
+// Returns false if the read does not fit (more keys than keytab holds, more passing keys than the
+// table and its global spill hold): the caller falls back to the plane tables.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void bitonic_sort_lds(lds_u32* e, uint32_t n) // n: power of two >= 64
+__device__ __forceinline__ uint32_t key_ordinal(const Acc& A, uint32_t rs)
 {
-  const uint32_t lane = lane_id();
-  if (n == 64) { // one element per lane: sort in registers
-    uint32_t v = e[lane];
-#pragma unroll
-    for (uint32_t k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        uint32_t o = __shfl_xor(v, j);
-        bool up = (lane & k) == 0, lower = (lane & j) == 0;
-        v = (lower == up) ? min(v, o) : max(v, o);
-      }
-    }
-    e[lane] = v;
-    WAVE_SYNC();
-    return;
-  }
-  for (uint32_t k = 2; k <= n; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t t = lane; t < (n >> 1); t += 64) {
-        uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), q = i + j;
-        uint32_t a = e[i], b = e[q];
-        bool up = (i & k) == 0;
-        if ((a > b) == up) {
-          e[i] = b;
-          e[q] = a;
-        }
-      }
-      WAVE_SYNC();
-    }
-  }
+  const uint32_t blk = rs >> 6;
+  const uint64_t bits = *(lds_u64*)(A.bitmap + 2u * blk);
+  return (uint32_t)A.pre[blk] + __popcll(bits & ((1ull << (rs & 63u)) - 1ull));
 }
 
 __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchOut& out, const Acc& A, WaveState& ws,
-                                                lds_u32* hist, uint32_t hist_words, uint32_t read, uint32_t onmers,
-                                                uint32_t filt0, uint32_t filt1)
+                                                lds_u32* lo, uint32_t lo_words, uint32_t read, uint32_t onmers,
+                                                uint32_t filt0, uint32_t filt1, uint32_t dbg)
 {
   const uint32_t lane = lane_id();
-  const uint64_t le = (2ull << lane) - 1ull, lt = (1ull << lane) - 1ull;
+  const uint64_t lt = (1ull << lane) - 1ull;
   const uint32_t nev = ws.nev;
   const uint32_t lim0 = 2u * filt0 + 1u, lim1 = 2u * filt1 + 1u; // u32 wrap keeps "none" = max
+  const uint32_t hw = (A.np + 3u) >> 2; // histogram words per key
+  const uint32_t ew = hw + 1u;          // table entry: packed counters, key
+  const uint32_t kw = kPlaneWords + hw; // batch words per key: position map, counters
   lds_u32* e = ws.ev;
-  uint32_t nrec = 0, nkeys = 0, npad = 0;
+  uint32_t nrec = 0;
+  bool fits = true;
+  // event i of the read (a 64-aligned tile is entirely in LDS or entirely spilled)
+  auto ev_at = [&](uint32_t t0, uint32_t i) -> uint32_t { return t0 < ws.ev_cap ? e[i] : gload(&ws.gev[i - ws.ev_cap]); };
+  uint32_t* gtab = ws.gev + ws.gev_cap;
   if (nev) {
-    npad = 64;
-    while (npad < nev) npad <<= 1;
-    for (uint32_t i = nev + lane; i < npad; i += 64) e[i] = 0xFFFFFFFFu;
-    WAVE_SYNC();
-    bitonic_sort_lds(e, npad);
-    // ---- distinct (leaf, strand) keys
+    if (nev > ws.ev_cap) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // spilled events are complete
+    // ---- 1. mark keys, ordinal prefix per 64-bit block
     for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
-      uint32_t i = t0 + lane;
-      bool kl = i < nev && (i == 0 || (e[i] >> 12) != (e[i - 1] >> 12));
-      nkeys += __popcll(__ballot(kl));
+      const uint32_t i = t0 + lane;
+      if (i < nev) {
+        const uint32_t rs = ev_at(t0, i) >> 12;
+        lds_or(&A.bitmap[rs >> 5], 1u << (rs & 31u));
+      }
     }
-    const uint32_t hw = (A.np + 3u) >> 2; // four 8-bit counters per word: a segment has <= 128 positions
-    if (nkeys * hw > hist_words) return false;
-    for (uint32_t i = lane; i < nkeys * hw; i += 64) hist[i] = 0;
     WAVE_SYNC();
-    // ---- histogram of the position leaders; key table written in place over the sorted events
-    uint32_t run = 0, carry = 0xFFFFFFFFu; // carry = last event of the previous tile (kept in a register:
-                                           // the key table is written over the events as we go)
-    for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
-      uint32_t i = t0 + lane;
-      bool valid = i < nev;
-      uint32_t v = valid ? e[i] : 0xFFFFFFFFu;
-      uint32_t pv = __shfl_up(v, 1);
-      if (lane == 0) pv = carry;
-      carry = __shfl(v, 63);
-      bool kl = valid && (i == 0 || (v >> 12) != (pv >> 12));
-      bool plead = valid && (i == 0 || (v >> 5) != (pv >> 5));
-      uint64_t km = __ballot(kl);
-      uint32_t ord = run + __popcll(km & le) - 1u; // ordinal of my key (ord <= i)
-      WAVE_SYNC();                                  // every lane holds its event before the table is written
-      if (kl) e[ord] = v >> 12;
-      if (plead)
-        __hip_atomic_fetch_add(&hist[ord * hw + ((v & 31u) >> 2)], 1u << (8u * (v & 3u)), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-      run += __popcll(km);
+    uint32_t nkeys = 0;
+    const uint32_t nblk = A.bm_words >> 1;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += 64) {
+      const uint32_t b = b0 + lane;
+      uint32_t c = b < nblk ? __popcll(*(lds_u64*)(A.bitmap + 2u * b)) : 0u;
+      uint32_t inc = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d);
+        if (lane >= (uint32_t)d) inc += o;
+      }
+      if (b < nblk) A.pre[b] = (uint16_t)(nkeys + inc - c);
+      nkeys += __shfl(inc, 63);
+    }
+    WAVE_SYNC();
+    // keytab[nkeys] at the top of the low region if that leaves room for 64 table entries, else in
+    // global scratch (reads with close to a thousand keys)
+    const bool kt_lds = nkeys + 64u * ew <= lo_words;
+    fits = kt_lds || nkeys <= ws.gkt_cap;
+    lds_u32* keytab = lo + lo_words - (kt_lds ? nkeys : 0u);
+    uint32_t* gkt = gtab + (uint64_t)ws.gtab_cap * ew;
+    const uint32_t tab_cap = (lo_words - (kt_lds ? nkeys : 0u)) / ew;
+    // ---- 2. ordinals into the events, keys into keytab; hd levels present
+    uint32_t lv = 0;
+    if (fits)
+      for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
+        const uint32_t i = t0 + lane;
+        if (i < nev) {
+          const uint32_t v = ev_at(t0, i), rs = v >> 12;
+          const uint32_t o = key_ordinal(A, rs);
+          const uint32_t nv = (o << 12) | (v & 0xFFFu);
+          if (t0 < ws.ev_cap)
+            e[i] = nv;
+          else
+            gstore(&ws.gev[i - ws.ev_cap], nv);
+          if (kt_lds)
+            keytab[o] = rs;
+          else
+            gstore(&gkt[o], rs);
+          lv |= 1u << (v & 31u);
+        }
+      }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) lv |= __shfl_xor(lv, d);
+    if (nev > ws.ev_cap || !kt_lds) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    WAVE_SYNC();
+    // the bitmap goes back to all-zero
+    if (fits) {
+      for (uint32_t o = lane; o < nkeys; o += 64) A.bitmap[(kt_lds ? keytab[o] : gload(&gkt[o])) >> 5] = 0;
+    } else {
+      for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
+        const uint32_t i = t0 + lane;
+        if (i < nev) A.bitmap[ev_at(t0, i) >> 17] = 0;
+      }
+      nkeys = 0;
+    }
+    if (dbg & 64u) nkeys = 0;
+    // ---- 3. batches of KB ordinals
+    const uint32_t nev_lds = (min(nev, ws.ev_cap) + 1u) & ~1u;
+    lds_u32* bt = e + nev_lds; // [KB][kw]
+    const uint32_t KB = (ws.ev_words - nev_lds) / kw;
+    for (uint32_t k0 = 0; k0 < nkeys; k0 += KB) {
+      const uint32_t kn = min(KB, nkeys - k0);
+      for (uint32_t i = lane; i < kn * kw; i += 64) bt[i] = 0;
+      WAVE_SYNC();
+      for (uint32_t h = 0; h < A.np; ++h) {
+        if (!((lv >> h) & 1u)) continue;
+        for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
+          const uint32_t i = t0 + lane;
+          const uint32_t v = i < nev ? ev_at(t0, i) : 0xFFFFFFFFu;
+          const uint32_t o = (v >> 12) - k0;
+          if ((v & 31u) == h && o < kn) {
+            const uint32_t pos = (v >> 5) & 127u, bit = 1u << (pos & 31u);
+            const uint32_t old = __hip_atomic_fetch_or(&bt[o * kw + (pos >> 5)], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!(old & bit))
+              __hip_atomic_fetch_add(&bt[o * kw + kPlaneWords + (h >> 2)], 1u << (8u * (h & 3u)), __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+        WAVE_SYNC();
+      }
+      // ---- 4. one lane per key of the batch
+      for (uint32_t j0 = 0; j0 < kn; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        uint32_t c[kHistWords]; // packed 8-bit counters, four hd values per word
+        bool ok = false;
+        uint32_t rs = 0;
+#pragma unroll
+        for (int q = 0; q < kHistWords; ++q) c[q] = 0;
+        if (j < kn) {
+#pragma unroll
+          for (int q = 0; q < kHistWords; ++q)
+            if ((uint32_t)q < hw) c[q] = bt[j * kw + kPlaneWords + q];
+          rs = kt_lds ? keytab[k0 + j] : gload(&gkt[k0 + j]);
+          uint32_t hmin = 0xFFFFFFFFu; // hdist_min = lowest hd with a non-zero counter
+#pragma unroll
+          for (int q = kHistWords - 1; q >= 0; --q)
+            if (c[q]) hmin = 4u * q + ((uint32_t)(__ffs((int)c[q]) - 1) >> 3);
+          ok = hmin <= ((rs & 1u) ? lim1 : lim0);
+        }
+        const uint64_t okm = __ballot(ok);
+        if (ok) {
+          const uint32_t t = nrec + __popcll(okm & lt);
+          if (t < tab_cap) {
+#pragma unroll
+            for (int q = 0; q < kHistWords; ++q)
+              if ((uint32_t)q < hw) lo[t * ew + q] = c[q];
+            lo[t * ew + hw] = rs;
+          } else if (t - tab_cap < ws.gtab_cap) {
+            uint32_t* g = gtab + (uint64_t)(t - tab_cap) * ew;
+#pragma unroll
+            for (int q = 0; q < kHistWords; ++q)
+              if ((uint32_t)q < hw) gstore(&g[q], c[q]);
+            gstore(&g[hw], rs);
+          }
+        }
+        nrec += __popcll(okm);
+      }
       WAVE_SYNC();
     }
-    // ---- records that pass `hdist_min <= 2*hdist_filt+1` (src/query.cpp:101-106,119)
-    for (uint32_t t0 = 0; t0 < nkeys; t0 += 64) {
-      uint32_t o = t0 + lane;
-      bool ok = false;
-      if (o < nkeys) {
-        uint32_t hmin = 0xFFFFFFFFu;
-        for (uint32_t x = 0; x < A.np; ++x)
-          if ((hist[o * hw + (x >> 2)] >> (8u * (x & 3u))) & 255u) {
-            hmin = x;
-            break;
-          }
-        ok = hmin <= ((e[o] & 1u) ? lim1 : lim0);
-      }
-      nrec += __popcll(__ballot(ok));
+    if (fits) {
+      fits = nrec <= tab_cap + ws.gtab_cap;
+      if (nrec > tab_cap) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
-  }
-  const uint32_t rbase = nrec ? alloc_records(out, ws, nrec) : 0u;
-  if (lane == 0) {
-    out.rd_off[read] = rbase == 0xFFFFFFFFu ? 0 : rbase;
-    out.rd_cnt[read] = rbase == 0xFFFFFFFFu ? 0 : nrec;
+    if (fits) {
+      const uint32_t rbase = nrec ? alloc_records(out, ws, nrec) : 0u;
+      if (lane == 0) {
+        out.rd_off[read] = rbase == 0xFFFFFFFFu ? 0 : rbase;
+        out.rd_cnt[read] = rbase == 0xFFFFFFFFu ? 0 : nrec;
+        out.rd_onmers[read] = onmers;
+        out.rd_filt[2 * read] = filt0;
+        out.rd_filt[2 * read + 1] = filt1;
+      }
+      if (nrec && rbase != 0xFFFFFFFFu) {
+        for (uint32_t t0 = 0; t0 < nrec; t0 += 64) {
+          const uint32_t t = t0 + lane;
+          if (t >= nrec) break;
+          const uint32_t ri = rbase + t;
+          const uint32_t* g = gtab + (uint64_t)(t - tab_cap) * ew;
+          const bool in_lds = t < tab_cap;
+          const uint32_t rs = in_lds ? lo[t * ew + hw] : gload(&g[hw]);
+          out.rec_read[ri] = read;
+          out.rec_key[ri] = (ix.leaf_se[rs >> 1] << 1) | (rs & 1u);
+          for (uint32_t x = 0; x < A.np; ++x) {
+            const uint32_t w = in_lds ? lo[t * ew + (x >> 2)] : gload(&g[x >> 2]);
+            out.rec_hist[(uint64_t)x * out.rec_cap + ri] = (w >> (8u * (x & 3u))) & 255u;
+          }
+        }
+      }
+    }
+  } else if (lane == 0) {
+    out.rd_off[read] = 0;
+    out.rd_cnt[read] = 0;
     out.rd_onmers[read] = onmers;
     out.rd_filt[2 * read] = filt0;
     out.rd_filt[2 * read + 1] = filt1;
   }
-  if (nrec && rbase != 0xFFFFFFFFu) {
-    const uint32_t hw = (A.np + 3u) >> 2;
-    uint32_t run = 0;
-    for (uint32_t t0 = 0; t0 < nkeys; t0 += 64) {
-      uint32_t o = t0 + lane;
-      bool ok = false;
-      uint32_t rs = 0;
-      if (o < nkeys) {
-        rs = e[o];
-        uint32_t hmin = 0xFFFFFFFFu;
-        for (uint32_t x = 0; x < A.np; ++x)
-          if ((hist[o * hw + (x >> 2)] >> (8u * (x & 3u))) & 255u) {
-            hmin = x;
-            break;
-          }
-        ok = hmin <= ((rs & 1u) ? lim1 : lim0);
-      }
-      uint64_t okm = __ballot(ok);
-      if (ok) {
-        uint32_t ri = rbase + run + __popcll(okm & lt);
-        out.rec_read[ri] = read;
-        out.rec_key[ri] = (ix.leaf_se[rs >> 1] << 1) | (rs & 1u);
-        for (uint32_t x = 0; x < A.np; ++x)
-          out.rec_hist[(uint64_t)x * out.rec_cap + ri] = (hist[o * hw + (x >> 2)] >> (8u * (x & 3u))) & 255u;
-      }
-      run += __popcll(okm);
-    }
-  }
-  // the event buffer aliases the plane tables: leave it zeroed
   WAVE_SYNC();
-  for (uint32_t i = lane; i < npad; i += 64) e[i] = 0;
-  WAVE_SYNC();
-  return true;
+  return fits;
 }
 
 // ---------------------------------------------------------------------------
 // One read.
 // ---------------------------------------------------------------------------
-template <int LOG_G, bool SL, bool TAP>
+template <int LOG_G, int CPL, bool SL, bool TAP>
 __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams& P, const BatchIn& in,
                                              const BatchOut& out, uint32_t read, const Acc& A, WaveState& ws,
                                              const ProbeList& pl, lds_u32* hist_tbl, uint32_t hist_words)
@@ -863,6 +974,15 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   // A read is processed once; only if its events do not fit (buffer or histogram table) is it
   // processed a second time with the plane tables.
   for (;;) {
+  if (ws.evmode) {
+    ws.dirty = true;
+  } else if (ws.dirty) { // the plane tables must start empty
+    WAVE_SYNC();
+    A.keys[lane] = 0;
+    for (uint32_t i = lane; i < ws.ev_words; i += 64) A.planes[i] = 0;
+    WAVE_SYNC();
+    ws.dirty = false;
+  }
   onmers = 0;
   filt0 = 0xFFFFFFFFu, filt1 = 0xFFFFFFFFu;
   ws.top = 0;
@@ -902,7 +1022,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
         pl.tag[i] = (64u * pp + lane) | (1u << 7) | (cur.lib1 << 8);
       }
       WAVE_SYNC();
-      if (!(P.dbg & 4u)) scan_list<LOG_G, SL, TAP>(ix, P, out, A, ws, pl, nact, filt0, filt1);
+      if (!(P.dbg & 4u)) scan_list<LOG_G, CPL, SL, TAP>(ix, P, out, A, ws, pl, nact, filt0, filt1);
       WAVE_SYNC();
       cur = nxt;
     }
@@ -930,12 +1050,10 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   if (ws.err && lane == 0) atomicOr(&out.counters[1], ws.err);
   ws.err = 0;
   if (!ws.evmode) break;
-  if (!ws.ev_full && finalize_events(ix, out, A, ws, hist_tbl, hist_words, read, onmers, filt0, filt1)) return;
-  // does not fit: zero the aliased region and redo the read with the plane tables
-  WAVE_SYNC();
-  for (uint32_t i = lane; i < (uint32_t)kLdsSlots * A.np * (kPlaneWords + 1); i += 64) A.planes[i] = 0;
-  WAVE_SYNC();
-  ws.evmode = false;
+  if (P.dbg & 16u) ws.nev = 0, ws.ev_full = false;
+  if ((P.dbg & 32u) && ws.ev_full) ws.nev = 0, ws.ev_full = false;
+  if (!ws.ev_full && finalize_events(ix, out, A, ws, hist_tbl, hist_words, read, onmers, filt0, filt1, P.dbg)) return;
+  ws.evmode = false; // does not fit: redo the read with the plane tables
   } // redo loop
   // records that pass `hdist_min <= 2*hdist_filt+1` (src/query.cpp:101-106,119), ordered by key so
   // that the two strands of a leaf are adjacent
@@ -1039,7 +1157,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   __syncthreads();
 }
 
-template <int LOG_G, bool SL, bool TAP>
+template <int LOG_G, int CPL, bool SL, bool TAP>
 __global__ __launch_bounds__(kWave, 4) void kr_probe_kernel_t(DevIndex ix, DevParams P, BatchIn in, BatchOut out)
 {
   // One carve of dynamic LDS (base is 16-byte aligned: no static __shared__ in front):
@@ -1058,6 +1176,7 @@ __global__ __launch_bounds__(kWave, 4) void kr_probe_kernel_t(DevIndex ix, DevPa
   A.planes = A.keys + kLdsSlots;
   A.counts = A.planes + kLdsSlots * P.np * kPlaneWords;
   A.bitmap = A.counts + kLdsSlots * P.np;
+  A.pre = (lds_u16*)(A.bitmap + out.bm_words);
   A.nslots2 = out.nslots2;
   A.bm_words = out.bm_words;
   const uint64_t w = blockIdx.x;
@@ -1091,8 +1210,15 @@ __global__ __launch_bounds__(kWave, 4) void kr_probe_kernel_t(DevIndex ix, DevPa
   ws.ev = A.planes; // planes + counts are contiguous: kLdsSlots * np * 5 words
   ws.ev_cap = 64;
   while (ws.ev_cap * 2 <= (uint32_t)kLdsSlots * P.np * (kPlaneWords + 1)) ws.ev_cap <<= 1;
+  if (ws.ev_cap == (uint32_t)kLdsSlots * P.np * (kPlaneWords + 1)) ws.ev_cap >>= 1;
+  ws.ev_words = (uint32_t)kLdsSlots * P.np * (kPlaneWords + 1);
+  ws.dirty = false;
+  ws.gev = A.g_list;
+  ws.gev_cap = out.ev_spill;
+  ws.gtab_cap = out.tab_spill;
+  ws.gkt_cap = out.kt_spill;
   ProbeList pl{s_bkt, s_q, s_tag};
-  for (uint32_t r = blockIdx.x; r < in.nreads; r += gridDim.x) process_read<LOG_G, SL, TAP>(ix, P, in, out, r, A, ws, pl, (lds_u32*)s_base, (kStackCap * 8 + kListCap * 16) / 4);
+  for (uint32_t r = blockIdx.x; r < in.nreads; r += gridDim.x) process_read<LOG_G, CPL, SL, TAP>(ix, P, in, out, r, A, ws, pl, (lds_u32*)s_base, (kStackCap * 8 + kListCap * 16) / 4 + kLdsSlots);
   if (ws.n_l2 && lane_id() == 0) atomicAdd(&out.counters[2], ws.n_l2);
   if (ws.n_rec && lane_id() == 0) atomicAdd(&out.counters[4], ws.n_rec);
 }
@@ -1178,68 +1304,92 @@ __device__ __forceinline__ double llh_eval(const LlhConst& C, const LlhTables& T
 }
 
 // boost::math::tools::brent_find_minima(f, 1e-10, 0.5, 16) (src/query.cpp:430);
-// published algorithm, see SURVEY.md Appendix B.
+// published algorithm, see SURVEY.md Appendix B.  The minimisation is written as a resumable state
+// machine -- one objective evaluation per step() -- so that the record kernel can hand a lane a new
+// record the moment its minimisation converges (the number of evaluations varies 10..23 between
+// records; a wave that waits for its slowest lane idles 40 % of its lanes).
+struct BrentState {
+  double x, w, v, fx, fw, fv, mn, mx, delta, delta2;
+  int it;
+};
+constexpr double kBrentTol = 0x1p-15; // ldexp(1, 1 - min(53/2, 16))
+
+// Before an evaluation: false if converged (result is x, fx), else the next abscissa in u.
+__device__ __forceinline__ bool brent_next(BrentState& s, double& u)
+{
+  const double golden = 0.3819660f;
+  const double mid = (s.mn + s.mx) / 2;
+  const double fract1 = kBrentTol * fabs(s.x) + kBrentTol / 4;
+  const double fract2 = 2 * fract1;
+  if (s.it >= 1000 || fabs(s.x - mid) <= (fract2 - (s.mx - s.mn) / 2)) return false;
+  ++s.it;
+  if (fabs(s.delta2) > fract1) {
+    double r = (s.x - s.w) * (s.fx - s.fv);
+    double q = (s.x - s.v) * (s.fx - s.fw);
+    double pp = (s.x - s.v) * q - (s.x - s.w) * r;
+    q = 2 * (q - r);
+    if (q > 0) pp = -pp;
+    q = fabs(q);
+    double td = s.delta2;
+    s.delta2 = s.delta;
+    if ((fabs(pp) >= fabs(q * td / 2)) || (pp <= q * (s.mn - s.x)) || (pp >= q * (s.mx - s.x))) {
+      s.delta2 = (s.x >= mid) ? s.mn - s.x : s.mx - s.x;
+      s.delta = golden * s.delta2;
+    } else {
+      s.delta = pp / q;
+      u = s.x + s.delta;
+      if (((u - s.mn) < fract2) || ((s.mx - u) < fract2)) s.delta = (mid - s.x) < 0 ? -fabs(fract1) : fabs(fract1);
+    }
+  } else {
+    s.delta2 = (s.x >= mid) ? s.mn - s.x : s.mx - s.x;
+    s.delta = golden * s.delta2;
+  }
+  u = (fabs(s.delta) >= fract1) ? (s.x + s.delta) : (s.delta > 0 ? (s.x + fabs(fract1)) : (s.x - fabs(fract1)));
+  return true;
+}
+// First evaluation (at the upper bracket end).
+__device__ __forceinline__ void brent_start(BrentState& s, double u, double fu)
+{
+  s.mn = 1e-10, s.mx = 0.5;
+  s.x = s.w = s.v = u;
+  s.fw = s.fv = s.fx = fu;
+  s.delta2 = s.delta = 0;
+  s.it = 0;
+}
+// After an evaluation at u.
+__device__ __forceinline__ void brent_update(BrentState& s, double u, double fu)
+{
+  if (fu <= s.fx) {
+    if (u >= s.x)
+      s.mn = s.x;
+    else
+      s.mx = s.x;
+    s.v = s.w, s.w = s.x, s.x = u;
+    s.fv = s.fw, s.fw = s.fx, s.fx = fu;
+  } else {
+    if (u < s.x)
+      s.mn = u;
+    else
+      s.mx = u;
+    if ((fu <= s.fw) || (s.w == s.x)) {
+      s.v = s.w, s.w = u;
+      s.fv = s.fw, s.fw = fu;
+    } else if ((fu <= s.fv) || (s.v == s.x) || (s.v == s.w)) {
+      s.v = u;
+      s.fv = fu;
+    }
+  }
+}
+
 template <int NPT>
 __device__ __forceinline__ void brent_min(const LlhConst& C, const LlhTables& T, const LlhProblem& p, double& d_out, double& v_out)
 {
-  double mn = 1e-10, mx = 0.5;
-  const double tolerance = 0x1p-15; // ldexp(1, 1 - min(53/2, 16))
-  const double golden = 0.3819660f;
-  double x, w, v, u, delta, delta2, fu, fv, fw, fx, mid, fract1, fract2;
-  x = w = v = mx;
-  fw = fv = fx = llh_eval<NPT>(C, T, p, x);
-  delta2 = delta = 0;
-  for (int it = 0; it < 1000; ++it) {
-    mid = (mn + mx) / 2;
-    fract1 = tolerance * fabs(x) + tolerance / 4;
-    fract2 = 2 * fract1;
-    if (fabs(x - mid) <= (fract2 - (mx - mn) / 2)) break;
-    if (fabs(delta2) > fract1) {
-      double r = (x - w) * (fx - fv);
-      double q = (x - v) * (fx - fw);
-      double pp = (x - v) * q - (x - w) * r;
-      q = 2 * (q - r);
-      if (q > 0) pp = -pp;
-      q = fabs(q);
-      double td = delta2;
-      delta2 = delta;
-      if ((fabs(pp) >= fabs(q * td / 2)) || (pp <= q * (mn - x)) || (pp >= q * (mx - x))) {
-        delta2 = (x >= mid) ? mn - x : mx - x;
-        delta = golden * delta2;
-      } else {
-        delta = pp / q;
-        u = x + delta;
-        if (((u - mn) < fract2) || ((mx - u) < fract2)) delta = (mid - x) < 0 ? -fabs(fract1) : fabs(fract1);
-      }
-    } else {
-      delta2 = (x >= mid) ? mn - x : mx - x;
-      delta = golden * delta2;
-    }
-    u = (fabs(delta) >= fract1) ? (x + delta) : (delta > 0 ? (x + fabs(fract1)) : (x - fabs(fract1)));
-    fu = llh_eval<NPT>(C, T, p, u);
-    if (fu <= fx) {
-      if (u >= x)
-        mn = x;
-      else
-        mx = x;
-      v = w, w = x, x = u;
-      fv = fw, fw = fx, fx = fu;
-    } else {
-      if (u < x)
-        mn = u;
-      else
-        mx = u;
-      if ((fu <= fw) || (w == x)) {
-        v = w, w = u;
-        fv = fw, fw = fu;
-      } else if ((fu <= fv) || (v == x) || (v == w)) {
-        v = u;
-        fv = fu;
-      }
-    }
-  }
-  d_out = x;
-  v_out = fx;
+  BrentState s;
+  double u = 0.5;
+  brent_start(s, u, llh_eval<NPT>(C, T, p, u));
+  while (brent_next(s, u)) brent_update(s, u, llh_eval<NPT>(C, T, p, u));
+  d_out = s.x;
+  v_out = s.fx;
 }
 
 template <int NPT>
@@ -1265,20 +1415,68 @@ __device__ __forceinline__ void load_problem(const LlhConst& C, const uint32_t* 
   p.rho = rho;
 }
 
+// One record per lane, refilled: a lane whose minimisation has converged stores its result and, once
+// kLlhRefill lanes are idle, the idle lanes take the next records of the wave's current chunk (chunks of
+// kLlhChunk records are handed out through counters[5]).  Every step evaluates the objective once for
+// all busy lanes.
+constexpr uint32_t kLlhChunkMax = 2048, kLlhRefill = 8;
 template <int NPT>
 __device__ __forceinline__ void llh_records(const LlhConst& C, const LlhTables& T, const DevIndex& ix, const BatchOut& out)
 {
-  uint32_t nrec = min(out.counters[0], out.rec_cap);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += gridDim.x * blockDim.x) {
-    uint32_t key = out.rec_key[i];
-    if (key == 0) continue; // hole at the end of a wave's record chunk
-    uint32_t read = out.rec_read[i];
-    LlhProblem p;
-    load_problem<NPT>(C, out.rec_hist + i, out.rec_cap, out.rd_onmers[read], ix.libs[0].rho[key >> 1], p);
-    double d, v;
-    brent_min<NPT>(C, T, p, d, v);
-    out.rec_d[i] = d;
-    out.rec_v[i] = v;
+  const uint32_t nrec = min(out.counters[0], out.rec_cap);
+  const uint32_t lane = lane_id();
+  const uint64_t lt = (1ull << lane) - 1ull;
+  // chunk size: about four chunks per wave, 64 .. kLlhChunkMax records
+  const uint32_t kLlhChunk = min(kLlhChunkMax, max(64u, (nrec / (gridDim.x * (blockDim.x / kWave) * 4u)) & ~63u));
+  uint32_t next = 0, end = 0; // wave-uniform cursor into the current chunk
+  bool more = true;           // wave-uniform: chunks may remain
+  bool busy = false, fresh = false;
+  uint32_t rec = 0;
+  LlhProblem p;
+  BrentState s;
+  for (;;) {
+    double u = 0.5;
+    if (busy && !brent_next(s, u)) {
+      out.rec_d[rec] = s.x;
+      out.rec_v[rec] = s.fx;
+      busy = false;
+    }
+    // ---- refill
+    const uint64_t idle = __ballot(!busy);
+    if (idle != 0 && (more || next < end) && ((uint32_t)__popcll(idle) >= kLlhRefill || idle == __ballot(true))) {
+      if (next == end) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&out.counters[5], kLlhChunk);
+        base = __shfl(base, 0);
+        next = min(base, nrec);
+        end = min(base + kLlhChunk, nrec);
+        more = base + kLlhChunk < nrec;
+      }
+      const uint32_t mine = next + __popcll(idle & lt);
+      if (!busy && mine < end) {
+        const uint32_t key = out.rec_key[mine];
+        if (key != 0) { // 0 = hole at the end of a probe wave's record chunk
+          rec = mine;
+          load_problem<NPT>(C, out.rec_hist + rec, out.rec_cap, out.rd_onmers[out.rec_read[rec]], ix.libs[0].rho[key >> 1], p);
+          busy = fresh = true;
+          u = 0.5;
+        }
+      }
+      next = min(end, next + (uint32_t)__popcll(idle));
+    }
+    if (__ballot(busy) == 0) {
+      if (!more && next == end) break;
+      continue;
+    }
+    // ---- one objective evaluation for every busy lane
+    if (busy) {
+      const double fu = llh_eval<NPT>(C, T, p, u);
+      if (fresh)
+        brent_start(s, u, fu);
+      else
+        brent_update(s, u, fu);
+      fresh = false;
+    }
   }
 }
 
@@ -1297,41 +1495,60 @@ __global__ __launch_bounds__(256) void kr_llh_kernel(LlhConst C, DevIndex ix, Ba
 // key = (se << 1) | strand.  Iteration order of the reference's maps is arbitrary; the
 // order used here (all forward leaves by ascending se, then all reverse ones) is the
 // oracle's, so `<=` ties resolve identically.
+// 32 lanes per read, one record per lane (reads have tens of records; all record arrays are read
+// coalesced).
+template <int NPT>
 __global__ __launch_bounds__(256) void kr_select_kernel(LlhConst C, DevIndex ix, DevParams P, BatchOut out,
                                                         uint32_t nreads)
 {
   __shared__ double s_bk[32], s_hnk[kMaxPlanes];
   LlhTables T{(lds_f64*)s_bk, (lds_f64*)s_hnk};
   llh_tables_init(C, T.bk, T.hnk);
-  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += gridDim.x * blockDim.x) {
-    uint32_t o = out.rd_off[r], n = out.rd_cnt[r];
-    // closest: last record in (strand, se) order with d <= best
-    double best = 1.7976931348623157e308;
-    int cl = -1;
-    for (int strand = 0; strand < 2; ++strand)
-      for (uint32_t i = o; i < o + n; ++i)
-        if ((out.rec_key[i] & 1u) == (uint32_t)strand && out.rec_d[i] <= best) {
-          best = out.rec_d[i];
-          cl = (int)i;
-        }
-    bool na = (n == 0) || (P.dmax_set && best > P.dist_max);
-    out.rd_na[r] = na ? 1 : 0;
+  constexpr uint32_t GL = 32, GPB = 256 / GL;
+  const uint32_t gl = threadIdx.x & (GL - 1u);
+  const double kMax = 1.7976931348623157e308;
+  for (uint32_t r = blockIdx.x * GPB + threadIdx.x / GL; r < nreads; r += gridDim.x * GPB) {
+    const uint32_t o = out.rd_off[r], n = out.rd_cnt[r];
+    // ---- closest: last record in (strand, se) order with d <= best, i.e. the smallest d and among
+    //      equal d the largest (strand, index)
+    double bd = kMax;
+    uint32_t bo = 0;
+    bool any = false;
+    for (uint32_t i = gl; i < n; i += GL) {
+      const double d = out.rec_d[o + i];
+      const uint32_t ord = ((out.rec_key[o + i] & 1u) << 31) | i;
+      if (d <= kMax && (!any || d < bd || (d == bd && ord > bo))) bd = d, bo = ord, any = true;
+    }
+#pragma unroll
+    for (int sft = GL / 2; sft >= 1; sft >>= 1) {
+      const double od = __shfl_xor(bd, sft, GL);
+      const uint32_t oo = __shfl_xor(bo, sft, GL);
+      const bool oa = __shfl_xor(any ? 1 : 0, sft, GL) != 0;
+      if (oa && (!any || od < bd || (od == bd && oo > bo))) bd = od, bo = oo, any = true;
+    }
+    const int cl = any ? (int)(o + (bo & 0x7FFFFFFFu)) : -1;
+    const double best = bd;
+    const bool na = (n == 0) || (P.dmax_set && best > P.dist_max);
+    if (gl == 0) out.rd_na[r] = na ? 1 : 0;
     LlhProblem pc;
     double vcl = 0;
+    uint32_t kcl = 0;
+    if (cl >= 0) kcl = out.rec_key[cl];
     if (cl >= 0 && !P.no_filter) {
-      load_problem<0>(C, out.rec_hist + cl, out.rec_cap, out.rd_onmers[r], ix.libs[0].rho[out.rec_key[cl] >> 1], pc);
+      load_problem<NPT>(C, out.rec_hist + cl, out.rec_cap, out.rd_onmers[r], ix.libs[0].rho[kcl >> 1], pc);
       vcl = out.rec_v[cl];
     }
-    for (uint32_t i = o; i < o + n; ++i) {
-      uint32_t key = out.rec_key[i];
+    for (uint32_t t = gl; t < n; t += GL) {
+      const uint32_t i = o + t;
+      const uint32_t key = out.rec_key[i];
       // which record represents this leaf in node_to_minfo?
       bool chosen;
-      bool has_other = (key & 1u) ? (i > o && out.rec_key[i - 1] == (key ^ 1u)) : (i + 1 < o + n && out.rec_key[i + 1] == (key ^ 1u));
+      const bool has_other = (key & 1u) ? (t > 0 && out.rec_key[i - 1] == (key ^ 1u)) : (t + 1 < n && out.rec_key[i + 1] == (key ^ 1u));
       if (!has_other) {
         chosen = true;
       } else {
-        uint32_t io = (key & 1u) ? i - 1 : i, ir = (key & 1u) ? i : i + 1;
-        double d_or = out.rec_d[io], d_rc = out.rec_d[ir];
+        const uint32_t io = (key & 1u) ? i - 1 : i, ir = (key & 1u) ? i : i + 1;
+        const double d_or = out.rec_d[io], d_rc = out.rec_d[ir];
         uint32_t m_or = 0, m_rc = 0;
         for (uint32_t x = 0; x <= C.th; ++x) {
           m_or += out.rec_hist[(uint64_t)x * out.rec_cap + io];
@@ -1339,20 +1556,20 @@ __global__ __launch_bounds__(256) void kr_select_kernel(LlhConst C, DevIndex ix,
         }
         bool take_or = (d_rc > d_or) || ((d_rc == d_or) && (m_rc < m_or)); // src/query.cpp:129-133
         // the closest overrides (src/query.cpp:136-138)
-        if (cl >= 0 && (out.rec_key[cl] >> 1) == (key >> 1)) take_or = ((uint32_t)cl == io);
+        if (cl >= 0 && (kcl >> 1) == (key >> 1)) take_or = ((uint32_t)cl == io);
         chosen = (key & 1u) ? !take_or : take_or;
       }
-      double d = out.rec_d[i];
+      const double d = out.rec_d[i];
       double chi = nan("");
       bool sel = false;
       if (chosen && !na) {
-        bool dm = !P.dmax_set || d < P.dist_max;
+        const bool dm = !P.dmax_set || d < P.dist_max;
         if (!P.multi) {
           sel = (int)i == cl;
         } else if (P.no_filter) {
           sel = dm;
         } else {
-          chi = 2 * (llh_eval<0>(C, T, pc, d) - vcl); // Minfo::likelihood_ratio (src/query.cpp:420-424)
+          chi = 2 * (llh_eval<NPT>(C, T, pc, d) - vcl); // Minfo::likelihood_ratio (src/query.cpp:420-424)
           sel = (chi < P.chisq) && dm;
         }
       }
@@ -1486,7 +1703,7 @@ __global__ void kr_relayout_inc(const uint64_t* inc, uint32_t nrows, uint64_t* b
 uint32_t probe_lds_bytes(uint32_t np, uint32_t bm_words)
 {
   uint32_t b = kStackCap * 8 + kListCap * 8 + 2 * kListCap * 4;
-  b += kLdsSlots * 4 + kLdsSlots * np * kPlaneWords * 4 + kLdsSlots * np * 4 + bm_words * 4;
+  b += kLdsSlots * 4 + kLdsSlots * np * kPlaneWords * 4 + kLdsSlots * np * 4 + bm_words * 4 + bm_words; // + u16 prefix per 2 words
   return (b + 15u) & ~15u;
 }
 
@@ -1671,7 +1888,7 @@ int kr_index_upload(const kr_index_view* v, int device, uint32_t flags, kr_index
     double nk = 0, nr = 0;
     for (uint32_t i = 0; i < v->nlibs; ++i) nk += (double)v->libs[i].nkmers, nr += (double)v->libs[i].nrows;
     double mean_len = nr > 0 ? nk / nr : 0; // empty buckets never reach the scan, so this underestimates slightly
-    H.log_g = mean_len <= 3.0 ? 0u : (mean_len <= 20.0 ? 2u : 3u);
+    H.log_g = mean_len <= 3.0 ? 0u : (mean_len <= 44.0 ? 2u : 3u);
     if (const char* e = getenv("KR_LOG_G")) H.log_g = (uint32_t)atoi(e) > 3 ? 3u : (uint32_t)atoi(e);
     if (H.log_g == 1) H.log_g = 2;
   }
@@ -1885,7 +2102,7 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
   // resident waves per CU: LDS-limited (160 KiB per CU), VGPR-limited to 4 waves per SIMD
-  const uint32_t nslots2 = std::max<uint32_t>(2u, 2u * ix->dix.nleaves), bm_words = (nslots2 + 31) / 32;
+  const uint32_t nslots2 = std::max<uint32_t>(2u, 2u * ix->dix.nleaves), bm_words = ((nslots2 + 63) / 64) * 2;
   uint32_t per_cu = std::min<uint32_t>(16u, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words));
   s->nwaves = (uint32_t)prop.multiProcessorCount * std::max<uint32_t>(1u, per_cu);
   // default record capacity: up to 2 * leaves per read, at most 16 per read on average
@@ -1923,7 +2140,10 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   o.rec_cap = s->rec_cap;
   o.hit_cap = s->hit_cap;
   o.nslots2 = nslots2;
-  const uint32_t g_list_words = std::max<uint32_t>(nslots2, (uint32_t)kLdsSlots * np * (kPlaneWords + 1));
+  o.ev_spill = kEvSpill;
+  o.tab_spill = std::min<uint32_t>(nslots2, 4096u);
+  o.kt_spill = std::min<uint32_t>(nslots2, 16384u);
+  const uint32_t g_list_words = std::max<uint32_t>(nslots2, o.ev_spill + o.tab_spill * ((np + 3) / 4 + 1) + o.kt_spill);
   o.g_list_words = g_list_words;
   o.bm_words = bm_words;
   SA(o.g_planes, (uint64_t)s->nwaves * nslots2 * np * kPlaneWords);
@@ -2002,25 +2222,25 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
   {
     const uint32_t lds = probe_lds_bytes(s->dp.np, s->out.bm_words);
     const bool tap = (flags & KR_TAP_HITS) != 0;
-#define KR_LAUNCH2(LG, SLV)                                                                                             \
+#define KR_LAUNCH2(LG, CP, SLV)                                                                                            \
   do {                                                                                                                 \
     if (tap)                                                                                                           \
-      hipLaunchKernelGGL((kr_probe_kernel_t<LG, SLV, true>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out); \
+      hipLaunchKernelGGL((kr_probe_kernel_t<LG, CP, SLV, true>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out); \
     else                                                                                                               \
-      hipLaunchKernelGGL((kr_probe_kernel_t<LG, SLV, false>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out); \
+      hipLaunchKernelGGL((kr_probe_kernel_t<LG, CP, SLV, false>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out); \
   } while (0)
-#define KR_LAUNCH(LG)          \
-  do {                         \
-    if (single)                \
-      KR_LAUNCH2(LG, true);    \
-    else                       \
-      KR_LAUNCH2(LG, false);   \
+#define KR_LAUNCH(LG, CP)          \
+  do {                             \
+    if (single)                    \
+      KR_LAUNCH2(LG, CP, true);    \
+    else                           \
+      KR_LAUNCH2(LG, CP, false);   \
   } while (0)
     const bool single = dix.nlibs == 1 && dix.m <= 64;
     switch (s->ix->log_g) {
-      case 0: KR_LAUNCH(0); break;
-      case 2: KR_LAUNCH(2); break;
-      default: KR_LAUNCH(3); break;
+      case 0: KR_LAUNCH(0, 2); break; // sparse tables: a lane per probe
+      case 2: KR_LAUNCH(2, 3); break; // 4 lanes x 3 chunks = 48 entries per pass
+      default: KR_LAUNCH(3, 3); break; // 8 lanes x 3 chunks = 96 entries per pass
     }
 #undef KR_LAUNCH2
 #undef KR_LAUNCH
@@ -2031,7 +2251,13 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
     hipLaunchKernelGGL(kr_llh_kernel<5>, dim3(2048), dim3(256), 0, st, s->llh, dix, s->out);
   else
     hipLaunchKernelGGL(kr_llh_kernel<0>, dim3(2048), dim3(256), 0, st, s->llh, dix, s->out);
-  hipLaunchKernelGGL(kr_select_kernel, dim3((nreads + 255) / 256), dim3(256), 0, st, s->llh, dix, s->dp, s->out, nreads);
+  {
+    const uint32_t sgrid = std::min<uint32_t>((nreads + 7) / 8, 16384u);
+    if (s->llh.th == 4)
+      hipLaunchKernelGGL(kr_select_kernel<5>, dim3(sgrid), dim3(256), 0, st, s->llh, dix, s->dp, s->out, nreads);
+    else
+      hipLaunchKernelGGL(kr_select_kernel<0>, dim3(sgrid), dim3(256), 0, st, s->llh, dix, s->dp, s->out, nreads);
+  }
   HIP_TRY(hipEventRecord(s->ev[4], st));
   HIP_TRY(hipGetLastError());
   return KR_OK;
