@@ -231,8 +231,8 @@ KR_API int kr_llh_batch(const kr_index*, uint32_t hdist_th, uint32_t mode, uint6
 /* Kernel timing of the last collected batch (HIP events on the stream's own stream). */
 typedef struct kr_timing {
   float ms_total;    /* first kernel start -> last kernel end                        */
-  float ms_probe;    /* kr_probe_kernel (LDS accumulators; the dominant kernel)      */
-  float ms_overflow; /* kr_probe_kernel, global-accumulator pass over overflow reads */
+  float ms_scan;     /* kr_scan_kernel: front end + table scan (the dominant kernel) */
+  float ms_acc;      /* kr_acc_kernel: colour expansion + histograms + records       */
   float ms_llh;      /* likelihood + selection kernels                               */
   float ms_h2d;      /* host->device copies (0 with KR_BASES_DEVICE)                 */
   uint32_t overflow_reads; /* reads that took the global-memory accumulator path     */

@@ -61,7 +61,7 @@ class KrHit(C.Structure):
 
 
 class KrTiming(C.Structure):
-    _fields_ = [("ms_total", C.c_float), ("ms_probe", C.c_float), ("ms_overflow", C.c_float), ("ms_llh", C.c_float),
+    _fields_ = [("ms_total", C.c_float), ("ms_scan", C.c_float), ("ms_acc", C.c_float), ("ms_llh", C.c_float),
                 ("ms_h2d", C.c_float), ("overflow_reads", C.c_uint32)]
 
 

@@ -32,6 +32,7 @@
 // Built with -ffp-contract=off: the reference is compiled for baseline x86-64 (no FMA,
 // makefile:7), and the likelihood follows its operation order.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "kr_common.h"
 #include "kr_devutil.h"
@@ -54,7 +55,8 @@ constexpr int kWave = 64;
 constexpr int kSegPos = 128;      // k-mer positions per segment = 4 plane words
 constexpr int kPlaneWords = kSegPos / 32;
 constexpr int kMaxLibs = 16;
-constexpr int kStackCap = 256;    // colour work stack (items of 8 B)
+constexpr int kStackCap = 256;    // colour work stack (items of 8 B) ...
+constexpr int kStackUse = kStackCap - 32; // ... whose last 32 slots (64 words) hold the scan's hit-chunk queue
 constexpr int kLdsSlots = 64;     // level-1 (LDS) accumulator slots per wave: lane t owns slot t in the epilogue
 constexpr int kLdsProbeMax = 8;   // bounded probe sequence of the level-1 table
 constexpr int kMaxPlanes = KR_MAX_HDIST_TH + 1;
@@ -99,6 +101,7 @@ struct DevParams {
 // Everything the kernels write for one batch.
 struct BatchOut {
   uint32_t* counters;    // [0] record slots handed out  [1] error flags  [2] reads that used level 2  [3] nhits(tap)  [4] records
+                         // [5] LLH chunk cursor  [6] item slots handed out
   uint32_t* rd_off;
   uint32_t* rd_cnt;
   uint32_t* rd_onmers;
@@ -114,6 +117,11 @@ struct BatchOut {
   uint32_t rec_cap;
   kr_hit* hits;
   uint32_t hit_cap;
+  // scan kernel -> accumulate kernel: resolved hits (colour, tag) of every read, contiguous per read
+  uint2* items;          // x = tagged colour id, y = pos(7) | strand<<7 | lib(4)<<8 | hd(5)<<12 | segment(14)<<17
+  uint32_t item_cap;
+  uint32_t* rd_it_off;
+  uint32_t* rd_it_cnt;
   // level-2 accumulator scratch, one region per resident wave
   uint32_t* g_planes; // [nwaves][nslots2][np][4]
   uint32_t* g_counts; // [nwaves][nslots2][np]
@@ -124,7 +132,7 @@ struct BatchOut {
   uint32_t bm_words;  // ceil(nslots2 / 32)
 };
 
-enum : uint32_t { kErrRecCap = 1u, kErrStack = 2u, kErrTable = 4u, kErrHitCap = 8u };
+enum : uint32_t { kErrRecCap = 1u, kErrStack = 2u, kErrTable = 4u, kErrHitCap = 8u, kErrItemCap = 16u };
 
 struct BatchIn {
   const uint8_t* bases;
@@ -277,10 +285,8 @@ struct Acc {
 __device__ __forceinline__ uint32_t gload(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void gstore(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Work-stack item (8 B).  hi = pos(7) | strand(1)<<7 | lib(4)<<8 | hd(5)<<12 | idx_hi(8)<<17 |
-// unresolved<<31.  Resolved: lo = colour id.  Unresolved (a fresh table hit whose colour has not
-// been fetched yet): lo | idx_hi<<32 = entry index into the library's se[] array.
-constexpr uint32_t kItemUnresolved = 0x80000000u;
+// Work-stack item (8 B): lo = tagged colour id, hi = pos(7) | strand(1)<<7 | lib(4)<<8 | hd(5)<<12.
+// The items the scan kernel hands over carry the read's segment number in hi bits 17..30.
 __device__ __forceinline__ uint32_t tag_pos(uint32_t t) { return t & 127u; }
 __device__ __forceinline__ uint32_t tag_strand(uint32_t t) { return (t >> 7) & 1u; }
 __device__ __forceinline__ uint32_t tag_lib(uint32_t t) { return (t >> 8) & 15u; }
@@ -291,8 +297,6 @@ struct WaveState {
   uint32_t top;   // wave-uniform
   bool l2;        // this lane sent something to level 2 during this read
   uint32_t err;
-  uint32_t read;  // for the hit tap
-  uint32_t base0; // first k-mer position of the current segment
   uint32_t rec_next, rec_end; // wave-private range of record slots (wave-uniform)
   uint32_t n_l2;              // reads of this wave that used level 2
   uint32_t n_rec;             // records this wave emitted
@@ -383,73 +387,56 @@ __device__ __forceinline__ void add_leaf_events(const Acc& A, WaveState& ws, boo
 // load per colour.
 constexpr uint32_t kColMask = 0x3FFFFFFFu;
 
-// Colour expansion (the BFS of src/query.cpp:369-387, order-free here): drain the work stack.
-template <bool SL, bool TAP>
-__device__ __forceinline__ void expand_all(const DevIndex& ix, const BatchOut& out, const Acc& A, WaveState& ws)
+// One step of the colour expansion (the BFS of src/query.cpp:369-387, order-free here) for one item
+// per lane: a leaf becomes an event, a colour that expands is looked up in se_to_pse and its two
+// parts become events or new work items.  The caller guarantees room for 128 pushes.
+template <bool SL>
+__device__ __forceinline__ void expand_step(const DevIndex& ix, const Acc& A, WaveState& ws, bool have, uint32_t se, uint32_t tag)
+{
+  const uint64_t lt = (1ull << lane_id()) - 1ull;
+  uint32_t c0 = 0, c1 = 0;
+  bool p0 = false, p1 = false;
+  bool f0 = false, f1 = false, f2 = false; // leaf updates found by this lane: the item, child 0, child 1
+  if (have) {
+    f0 = (se >> 30) == 1u;
+    if ((se >> 30) == 2u) {
+      const uint2 pr = get_lib<SL>(ix, tag_lib(tag)).pse[se & kColMask];
+      c0 = pr.x;
+      c1 = pr.y;
+      f1 = (c0 >> 30) == 1u, p0 = (c0 >> 30) == 2u;
+      f2 = (c1 >> 30) == 1u, p1 = (c1 >> 30) == 2u;
+    }
+  }
+  add_leaf_events(A, ws, f0, make_event(se & kColMask, tag));
+  add_leaf_events(A, ws, f1, make_event(c0 & kColMask, tag));
+  add_leaf_events(A, ws, f2, make_event(c1 & kColMask, tag));
+  const uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
+  if (p0) ws.stack[ws.top + __popcll(m0 & lt)] = (uint64_t)c0 | ((uint64_t)tag << 32);
+  ws.top += __popcll(m0);
+  if (p1) ws.stack[ws.top + __popcll(m1 & lt)] = (uint64_t)c1 | ((uint64_t)tag << 32);
+  ws.top += __popcll(m1);
+  WAVE_SYNC();
+}
+
+// drain the work stack
+template <bool SL>
+__device__ __forceinline__ void expand_all(const DevIndex& ix, const Acc& A, WaveState& ws)
 {
   const uint32_t lane = lane_id();
-  const uint64_t lt = (1ull << lane) - 1ull;
   while (ws.top > 0) {
-    uint32_t room = kStackCap - ws.top;
-    uint32_t n = min(min(64u, ws.top), room);
+    const uint32_t room = kStackUse - ws.top;
+    const uint32_t n = min(min(64u, ws.top), room);
     if (n == 0) { // cannot make progress: report, drop the rest
       ws.err |= kErrStack;
       ws.top = 0;
       break;
     }
-    uint32_t base = ws.top - n;
-    bool have = lane < n;
-    uint2 item = make_uint2(0, 0);
-    if (have) {
-      uint64_t raw = ws.stack[base + lane];
-      item = make_uint2((uint32_t)raw, (uint32_t)(raw >> 32));
-    }
+    const uint32_t base = ws.top - n;
+    const bool have = lane < n;
+    uint64_t raw = 0;
+    if (have) raw = ws.stack[base + lane];
     ws.top = base;
-    uint32_t se = item.x, tag = item.y;
-    uint32_t c0 = 0, c1 = 0;
-    bool p0 = false, p1 = false;
-    bool f0 = false, f1 = false, f2 = false; // leaf updates found by this lane: the item, child 0, child 1
-    if (have) {
-      DevLib L = get_lib<SL>(ix, tag_lib(tag));
-      if (tag & kItemUnresolved) { // fetch the colour of a fresh hit
-        uint64_t idx = (uint64_t)item.x | ((uint64_t)((tag >> 17) & 0xFFu) << 32);
-        se = L.se[idx];
-        if (TAP) {
-          uint32_t hix = atomicAdd(&out.counters[3], 1u);
-          if (hix < out.hit_cap) {
-            kr_hit h;
-            h.read = ws.read;
-            h.kpos = ws.base0 + tag_pos(tag);
-            h.strand = tag_strand(tag);
-            h.lib = tag_lib(tag);
-            h.cmer_index = idx;
-            h.hd = tag_hd(tag);
-            h.se = (se >> 30) == 1u ? ix.leaf_se[se & kColMask] : (se & kColMask);
-            out.hits[hix] = h;
-          } else {
-            atomicOr(&out.counters[1], kErrHitCap);
-          }
-        }
-        tag &= 0x1FFFFu;
-      }
-      f0 = (se >> 30) == 1u;
-      if ((se >> 30) == 2u) {
-        uint2 pr = L.pse[se & kColMask];
-        c0 = pr.x;
-        c1 = pr.y;
-        f1 = (c0 >> 30) == 1u, p0 = (c0 >> 30) == 2u;
-        f2 = (c1 >> 30) == 1u, p1 = (c1 >> 30) == 2u;
-      }
-    }
-    add_leaf_events(A, ws, f0, make_event(se & kColMask, tag));
-    add_leaf_events(A, ws, f1, make_event(c0 & kColMask, tag));
-    add_leaf_events(A, ws, f2, make_event(c1 & kColMask, tag));
-    uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
-    if (p0) ws.stack[ws.top + __popcll(m0 & lt)] = (uint64_t)c0 | ((uint64_t)tag << 32);
-    ws.top += __popcll(m0);
-    if (p1) ws.stack[ws.top + __popcll(m1 & lt)] = (uint64_t)c1 | ((uint64_t)tag << 32);
-    ws.top += __popcll(m1);
-    WAVE_SYNC();
+    expand_step<SL>(ix, A, ws, have, (uint32_t)raw, (uint32_t)(raw >> 32));
   }
 }
 
@@ -505,139 +492,270 @@ __device__ __forceinline__ uint32_t chunk_hits(uint4 v, int lo, int hi, uint32_t
   return m & in;
 }
 
-// Scan the listed buckets: G = 2^LOG_G consecutive lanes share one probe and read consecutive
-// aligned 16-byte chunks of its bucket (G*16 contiguous bytes per step); 64/G probes per pass;
-// CPL chunks per lane per pass, and the loads of the NEXT pass are issued before the current
-// pass is examined (software pipeline: 2*CPL 16-byte loads in flight per lane).  No search, no
-// prefix sums: the probe of a lane is fixed by its lane id.  A pass covers G*CPL*4 entries of each
-// bucket; longer buckets take extra (unpipelined) rounds.
-template <int CPL>
-struct ScanStep {
-  uint64_t e_al;  // aligned entry index of the bucket's first chunk
-  int rel0, tot;  // bucket = entries [rel0, tot) relative to e_al
-  uint32_t q, tg, nch;
-  uint4 v[CPL];
+// ---------------------------------------------------------------------------
+// Kernel 1: the table scan.  One wave per read; per group of 64 positions the wave builds the probe
+// list (front end + bucket descriptors) and scans the listed buckets: G = 2^LOG_G consecutive lanes
+// share one probe and read consecutive aligned 16-byte chunks of its bucket (G*16 contiguous bytes per
+// step), 64/G probes per pass, CPL chunks per lane per pass.  No search, no prefix sums: the probe of a
+// lane is fixed by its lane id.  A pass covers G*CPL*4 entries of each bucket; longer buckets take
+// extra rounds.  The kernel keeps no accumulator state, so it runs at 8 waves per SIMD and hides the
+// HBM latency of its dependent steps (descriptor -> bucket -> colour) by occupancy alone.
+//
+// The scan proper only asks, per chunk, "is the smallest of the four Hamming distances within th?"
+// (hits are ~1 % of the entries) and keeps the answers as one bit per (pass, chunk) in a per-lane
+// register.  After the group's last pass the hit chunks of all lanes are dealt out again, one per
+// lane: the lane re-reads its chunk (L2), applies the bucket bounds, fetches the colour of every
+// matching entry and appends (colour, tag) items to the read's item list in HBM, which the
+// accumulate kernel consumes.
+// ---------------------------------------------------------------------------
+struct ScanWave {
+  uint32_t it_next, it_end; // wave-private range of item slots (wave-uniform)
+  uint32_t rd_start;        // first item of the current read
+  uint32_t err;
+  uint32_t filt0, filt1;    // per-lane running min hd per strand (hdist_filt, src/query.cpp:366-368)
 };
+constexpr uint32_t kItemChunk = 2048;
 
-template <int LOG_G, int CPL, bool SL>
-__device__ __forceinline__ void scan_issue(const DevIndex& ix, const ProbeList& pl, uint32_t nact, uint32_t p0, ScanStep<CPL>& S)
+// Make room for n more items directly behind the current read's items (wave-uniform).
+__device__ __forceinline__ bool item_reserve(const BatchOut& out, ScanWave& sw, uint32_t n)
 {
-  constexpr uint32_t G = 1u << LOG_G;
-  const uint32_t lane = lane_id();
-  const uint32_t sub = lane & (G - 1u), pi = p0 + (lane >> LOG_G);
-  const bool on = pi < nact;
-  const uint64_t b = on ? pl.bkt[pi] : 0ull;
-  S.q = on ? pl.q[pi] : 0u;
-  S.tg = on ? pl.tag[pi] : 0u;
-  const uint64_t st = b >> 24;
-  const uint32_t ln = (uint32_t)(b & 0xFFFFFFu);
-  S.e_al = st & ~3ull;
-  S.rel0 = (int)(st & 3u);
-  S.tot = S.rel0 + (int)ln;
-  S.nch = on ? (uint32_t)(S.tot + 3) >> 2 : 0u;
-  const uint32_t* enc = get_lib<SL>(ix, tag_lib(S.tg)).enc + S.e_al;
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) {
-    const uint32_t c = sub + (uint32_t)j * G;
-    S.v[j] = make_uint4(0, 0, 0, 0);
-    if (c < S.nch) S.v[j] = *reinterpret_cast<const uint4*>(enc + 4u * c);
+  if (sw.it_next + n <= sw.it_end) return true;
+  const uint32_t have = sw.it_next - sw.rd_start;
+  const uint32_t size = have + n + kItemChunk;
+  uint32_t base = 0;
+  if (lane_id() == 0) base = atomicAdd(&out.counters[6], size);
+  base = __shfl(base, 0);
+  if ((uint64_t)base + size > out.item_cap) {
+    sw.err |= kErrItemCap;
+    return false;
   }
-}
-
-struct Hds3 { uint32_t a, b, c; }; // per-chunk Hamming distances (4 x 8 bit) of up to 3 chunks, kept in registers
-
-// push hits as unresolved work items: pend = hit mask (4 bits per chunk), hds[j] the chunk's distances,
-// chunk j of this lane starts at entry e_al + 4 * (c0 + j*G)
-template <int LOG_G, int CPL, bool SL, bool TAP>
-__device__ __forceinline__ void push_hits(const DevIndex& ix, const BatchOut& out, const Acc& A, WaveState& ws, uint32_t tg,
-                                          uint64_t e_al, uint32_t c0, uint32_t pend, Hds3 hds, uint32_t& filt0,
-                                          uint32_t& filt1)
-{
-  constexpr uint32_t G = 1u << LOG_G;
-  const uint32_t lane = lane_id();
-  const uint64_t lt = (1ull << lane) - 1ull;
-  while (__ballot(pend != 0) != 0) {
-    if (ws.top > (uint32_t)(kStackCap - 64)) expand_all<SL, TAP>(ix, out, A, ws);
-    const bool has = pend != 0;
-    const uint32_t bit = has ? (uint32_t)__ffs((int)pend) - 1u : 0u;
-    const uint32_t e = bit & 3u, j = bit >> 2;
-    const uint64_t hm = __ballot(has);
-    if (has) {
-      uint32_t hw = hds.a;
-      if (CPL > 1) hw = j == 1u ? hds.b : hw;
-      if (CPL > 2) hw = j == 2u ? hds.c : hw;
-      const uint32_t hd = (hw >> (8 * e)) & 31u;
-      const uint64_t idx = e_al + 4ull * (c0 + j * G) + e;
-      if (tag_strand(tg))
-        filt1 = min(filt1, hd);
-      else
-        filt0 = min(filt0, hd);
-      ws.stack[ws.top + __popcll(hm & lt)] =
-        (uint64_t)(uint32_t)idx | ((uint64_t)(tg | (hd << 12) | ((uint32_t)(idx >> 32) << 17) | kItemUnresolved) << 32);
-      pend &= pend - 1u;
+  if (have) { // the read's items so far move to the new chunk (they were written by this wave: read them from L2)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    for (uint32_t i = lane_id(); i < have; i += 64) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(out.items + sw.rd_start + i);
+      out.items[base + i] = make_uint2(gload(src), gload(src + 1));
     }
-    ws.top += __popcll(hm);
-    WAVE_SYNC();
+  }
+  sw.rd_start = base;
+  sw.it_next = base + have;
+  sw.it_end = base + size;
+  return true;
+}
+
+// Entries `pend` (4-bit mask) of chunk c of the bucket at e_al matched: fetch their colours, append items.
+template <bool SL, bool TAP>
+__device__ __forceinline__ void emit_hits(const DevIndex& ix, const BatchOut& out, ScanWave& sw, uint32_t read, uint32_t base0,
+                                          uint32_t tg, uint64_t e_al, uint32_t c, uint32_t pend, uint32_t hds)
+{
+  const uint64_t lt = (1ull << lane_id()) - 1ull;
+  const uint32_t seg = base0 >> 7;
+  while (__ballot(pend != 0) != 0) {
+    const bool has = pend != 0;
+    const uint32_t e = has ? (uint32_t)__ffs((int)pend) - 1u : 0u;
+    const uint32_t hd = (hds >> (8u * e)) & 31u;
+    const uint64_t idx = e_al + 4ull * c + e;
+    uint32_t se = 0;
+    if (has) {
+      se = get_lib<SL>(ix, tag_lib(tg)).se[idx];
+      if (tag_strand(tg))
+        sw.filt1 = min(sw.filt1, hd);
+      else
+        sw.filt0 = min(sw.filt0, hd);
+      if (TAP) {
+        const uint32_t hix = atomicAdd(&out.counters[3], 1u);
+        if (hix < out.hit_cap) {
+          kr_hit h;
+          h.read = read;
+          h.kpos = base0 + tag_pos(tg);
+          h.strand = tag_strand(tg);
+          h.lib = tag_lib(tg);
+          h.cmer_index = idx;
+          h.hd = hd;
+          h.se = (se >> 30) == 1u ? ix.leaf_se[se & kColMask] : (se & kColMask);
+          out.hits[hix] = h;
+        } else {
+          atomicOr(&out.counters[1], kErrHitCap);
+        }
+      }
+    }
+    const bool keep = has && (se >> 30) != 0u; // class 0: empty colour / null tree node
+    const uint64_t km = __ballot(keep);
+    if (km != 0 && item_reserve(out, sw, (uint32_t)__popcll(km))) {
+      if (keep) out.items[sw.it_next + __popcll(km & lt)] = make_uint2(se, (tg & 0xFFFu) | (hd << 12) | (seg << 17));
+      sw.it_next += (uint32_t)__popcll(km);
+    }
+    pend &= pend - 1u;
   }
 }
 
+// Scan of one group's probe list.  Step s of the scan = (pass p0, chunk block cb): lane l looks at chunk
+// (l mod G) + cb*G of probe p0 + l/G and records in bit s of `hitbits` whether it holds an entry
+// within th; stepinfo[s] (LDS, wave-uniform) remembers (p0, cb*G).  When the group is done -- or the
+// bits are used up, for very long buckets -- the hit chunks are dealt out and resolved.
 template <int LOG_G, int CPL, bool SL, bool TAP>
-__device__ __forceinline__ void scan_list(const DevIndex& ix, const DevParams& P, const BatchOut& out, const Acc& A,
-                                          WaveState& ws, const ProbeList& pl, uint32_t nact, uint32_t& filt0,
-                                          uint32_t& filt1)
+__device__ __forceinline__ void scan_group(const DevIndex& ix, const DevParams& P, const BatchOut& out, ScanWave& sw,
+                                           const ProbeList& pl, lds_u32* queue, lds_u32* stepinfo, uint32_t nact, uint32_t read,
+                                           uint32_t base0)
 {
   constexpr uint32_t G = 1u << LOG_G, PPS = 64u >> LOG_G;
-  const uint32_t sub = lane_id() & (G - 1u);
-  if (nact == 0) return;
-  ScanStep<CPL> cur, nxt;
-  scan_issue<LOG_G, CPL, SL>(ix, pl, nact, 0, cur);
-  for (uint32_t p0 = 0; p0 < nact; p0 += PPS) {
-    nxt = cur;
-    if (p0 + PPS < nact) scan_issue<LOG_G, CPL, SL>(ix, pl, nact, p0 + PPS, nxt);
-    // ---- first CPL chunks per lane of every probe of this pass (already loaded)
-    {
-      uint32_t pend = 0;
-      Hds3 hds{0, 0, 0};
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        const int c = (int)(sub + (uint32_t)j * G);
-        uint32_t h = 0;
-        if ((uint32_t)c < cur.nch) pend |= chunk_hits(cur.v[j], cur.rel0 - 4 * c, cur.tot - 4 * c, cur.q, P.th, h) << (4 * j);
-        if (j == 0) hds.a = h;
-        if (j == 1) hds.b = h;
-        if (j == 2) hds.c = h;
-      }
-      if (P.dbg & 1u) pend = 0;
-      push_hits<LOG_G, CPL, SL, TAP>(ix, out, A, ws, cur.tg, cur.e_al, sub, pend, hds, filt0, filt1);
-    }
-    // ---- buckets longer than G*CPL chunks: the rest, CPL chunks per lane at a time
-    if (__ballot(cur.nch > G * CPL) != 0) {
-      const uint32_t* enc = get_lib<SL>(ix, tag_lib(cur.tg)).enc + cur.e_al;
-      for (uint32_t c0 = sub + G * CPL; __ballot(c0 < cur.nch) != 0; c0 += G * CPL) {
+  constexpr uint32_t kBits = 64u / CPL * CPL; // steps per flush
+  const uint32_t lane = lane_id(), sub = lane & (G - 1u);
+  uint32_t p0 = 0, cb = 0; // scan position: pass start, chunk block (units of G chunks)
+  while (p0 < nact) {
+    // ---- scan until the group is done or the step bits are used up
+    uint64_t hitbits = 0;
+    uint32_t step = 0;
+    while (p0 < nact && step < kBits) {
+      const uint32_t pi = p0 + (lane >> LOG_G);
+      const bool on = pi < nact;
+      const uint64_t b = on ? pl.bkt[pi] : 0ull;
+      const uint32_t q = on ? pl.q[pi] : 0u;
+      const uint64_t st = b >> 24;
+      const uint32_t tot = (uint32_t)(st & 3u) + (uint32_t)(b & 0xFFFFFFu);
+      const uint32_t nch = on ? (tot + 3u) >> 2 : 0u;
+      const uint32_t* enc = get_lib<SL>(ix, SL ? 0u : tag_lib(pl.tag[on ? pi : 0u])).enc + (st & ~3ull);
+      for (; step < kBits && __ballot(sub + cb * G < nch) != 0; cb += CPL, step += CPL) {
+        if (lane < (uint32_t)CPL) stepinfo[step + lane] = p0 | (((cb + lane) * G) << 8);
         uint4 v[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-          const uint32_t c = c0 + (uint32_t)j * G;
+          const uint32_t c = sub + (cb + (uint32_t)j) * G;
           v[j] = make_uint4(0, 0, 0, 0);
-          if (c < cur.nch) v[j] = *reinterpret_cast<const uint4*>(enc + 4u * c);
+          if (c < nch) v[j] = *reinterpret_cast<const uint4*>(enc + 4u * c);
         }
-        uint32_t pend = 0;
-        Hds3 hds{0, 0, 0};
+        // entries of the neighbouring buckets in the first / last chunk may give false positives, rejected below
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-          const int c = (int)(c0 + (uint32_t)j * G);
-          uint32_t h = 0;
-          if ((uint32_t)c < cur.nch) pend |= chunk_hits(v[j], cur.rel0 - 4 * c, cur.tot - 4 * c, cur.q, P.th, h) << (4 * j);
-          if (j == 0) hds.a = h;
-          if (j == 1) hds.b = h;
-          if (j == 2) hds.c = h;
+          const uint32_t m = min(min(hd_lr32(v[j].x, q), hd_lr32(v[j].y, q)), min(hd_lr32(v[j].z, q), hd_lr32(v[j].w, q)));
+          if (m <= P.th && sub + (cb + (uint32_t)j) * G < nch) hitbits |= 1ull << (step + (uint32_t)j);
         }
-        if (P.dbg & 1u) pend = 0;
-        push_hits<LOG_G, CPL, SL, TAP>(ix, out, A, ws, cur.tg, cur.e_al, c0, pend, hds, filt0, filt1);
       }
+      if (__ballot(sub + cb * G < nch) == 0) p0 += PPS, cb = 0; // pass finished
     }
-    cur = nxt;
+    if (P.dbg & 1u) hitbits = 0;
+    // ---- deal the hit chunks out, 64 at a time: re-read the chunk, apply the bucket bounds, emit
+    const uint32_t cnt = (uint32_t)__popcll(hitbits);
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d);
+      if (lane >= (uint32_t)d) inc += o;
+    }
+    const uint32_t H = __shfl(inc, 63);
+    uint64_t hb = hitbits;
+    uint32_t slot = inc - cnt;
+    WAVE_SYNC();
+    for (uint32_t w0 = 0; w0 < H; w0 += 64) {
+      while (__ballot(hb != 0 && slot < w0 + 64u) != 0) {
+        if (hb != 0 && slot < w0 + 64u) {
+          const uint32_t si = stepinfo[(uint32_t)__ffsll((long long)hb) - 1u];
+          queue[slot - w0] = ((si & 255u) + (lane >> LOG_G)) | ((sub + (si >> 8)) << 8);
+          hb &= hb - 1;
+          ++slot;
+        }
+      }
+      WAVE_SYNC();
+      uint32_t pend = 0, hds = 0, tg = 0, c = 0;
+      uint64_t e_al = 0;
+      if (lane < min(64u, H - w0)) {
+        const uint32_t d = queue[lane], probe = d & 255u;
+        c = d >> 8;
+        const uint64_t b = pl.bkt[probe];
+        const uint32_t q = pl.q[probe];
+        tg = pl.tag[probe];
+        const uint64_t st = b >> 24;
+        e_al = st & ~3ull;
+        const int rel0 = (int)(st & 3u), tot = rel0 + (int)(uint32_t)(b & 0xFFFFFFu);
+        const uint4 v = *reinterpret_cast<const uint4*>(get_lib<SL>(ix, tag_lib(tg)).enc + e_al + 4u * c);
+        pend = chunk_hits(v, rel0 - 4 * (int)c, tot - 4 * (int)c, q, P.th, hds);
+      }
+      WAVE_SYNC();
+      emit_hits<SL, TAP>(ix, out, sw, read, base0, tg, e_al, c, pend, hds);
+    }
   }
+}
+
+template <int LOG_G, int CPL, bool SL, bool TAP>
+__device__ __forceinline__ void scan_read(const DevIndex& ix, const DevParams& P, const BatchIn& in, const BatchOut& out,
+                                          uint32_t read, ScanWave& sw, const ProbeList& pl, lds_u32* queue, lds_u32* stepinfo)
+{
+  const uint32_t lane = lane_id();
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const uint64_t off0 = in.offsets[read], off1 = in.offsets[read + 1];
+  const uint8_t* seq = in.bases + off0;
+  const uint64_t len = off1 - off0;
+  const uint32_t k = ix.k;
+  const uint64_t nkm = len >= k ? len - k + 1 : 0; // enmers (src/query.cpp:42)
+  uint32_t onmers = 0;
+  sw.rd_start = sw.it_next;
+  sw.filt0 = 0xFFFFFFFFu, sw.filt1 = 0xFFFFFFFFu;
+  for (uint64_t base0 = 0; base0 < nkm; base0 += kSegPos) {
+    const uint32_t npos_seg = (uint32_t)min((uint64_t)kSegPos, nkm - base0);
+    SegBits sb;
+    load_segment(seq, len, base0, sb);
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) { // unrolled: SegBits stays in scalar registers
+      if (pp == 1 && npos_seg <= 64) break;
+      uint32_t nv = 0;
+      const Cand cur = fetch_group<SL>(ix, sb, pp, npos_seg, nv);
+      onmers += nv;
+      // ---- compact the non-empty probes of this group into the LDS list
+      const bool a0 = (cur.b0 & 0xFFFFFFu) != 0, a1 = (cur.b1 & 0xFFFFFFu) != 0;
+      const uint64_t m0 = __ballot(a0), m1 = __ballot(a1);
+      const uint32_t n0 = __popcll(m0), nact = n0 + __popcll(m1);
+      if (a0) {
+        const uint32_t i = __popcll(m0 & lt);
+        pl.bkt[i] = cur.b0;
+        pl.q[i] = cur.q0;
+        pl.tag[i] = (64u * pp + lane) | (cur.lib0 << 8);
+      }
+      if (a1) {
+        const uint32_t i = n0 + __popcll(m1 & lt);
+        pl.bkt[i] = cur.b1;
+        pl.q[i] = cur.q1;
+        pl.tag[i] = (64u * pp + lane) | (1u << 7) | (cur.lib1 << 8);
+      }
+      WAVE_SYNC();
+      if (!(P.dbg & 4u)) scan_group<LOG_G, CPL, SL, TAP>(ix, P, out, sw, pl, queue, stepinfo, nact, read, (uint32_t)base0);
+      WAVE_SYNC();
+    }
+  }
+  // ---- per-strand hdist_filt = min hd over kept table entries (src/query.cpp:366-368)
+  uint32_t f0 = sw.filt0, f1 = sw.filt1;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    f0 = min(f0, (uint32_t)__shfl_xor(f0, d));
+    f1 = min(f1, (uint32_t)__shfl_xor(f1, d));
+  }
+  if (lane == 0) {
+    out.rd_it_off[read] = sw.rd_start;
+    out.rd_it_cnt[read] = sw.it_next - sw.rd_start;
+    out.rd_onmers[read] = onmers;
+    out.rd_filt[2 * read] = f0;
+    out.rd_filt[2 * read + 1] = f1;
+  }
+}
+
+#ifndef KR_SCAN_WPE
+#define KR_SCAN_WPE 6 // resident scan waves per SIMD the register allocation is sized for (8 spills, 5 hides less latency)
+#endif
+constexpr int kScanWaves = 4; // waves per workgroup of the scan kernel (they share nothing)
+template <int LOG_G, int CPL, bool SL, bool TAP>
+__global__ __launch_bounds__(kScanWaves* kWave, KR_SCAN_WPE) void kr_scan_kernel_t(DevIndex ix, DevParams P, BatchIn in, BatchOut out)
+{
+  __shared__ __attribute__((aligned(16))) uint64_t s_bkt[kScanWaves][kListCap];
+  __shared__ uint32_t s_q[kScanWaves][kListCap], s_tag[kScanWaves][kListCap], s_queue[kScanWaves][64], s_step[kScanWaves][64];
+  const uint32_t w = threadIdx.x / kWave;
+  ProbeList pl{(lds_u64*)s_bkt[w], (lds_u32*)s_q[w], (lds_u32*)s_tag[w]};
+  lds_u32* queue = (lds_u32*)s_queue[w];
+  lds_u32* stepinfo = (lds_u32*)s_step[w];
+  ScanWave sw;
+  sw.it_next = sw.it_end = sw.rd_start = 0;
+  sw.err = 0;
+  sw.filt0 = sw.filt1 = 0xFFFFFFFFu;
+  const uint32_t nw = gridDim.x * kScanWaves;
+  for (uint32_t r = blockIdx.x * kScanWaves + w; r < in.nreads; r += nw) scan_read<LOG_G, CPL, SL, TAP>(ix, P, in, out, r, sw, pl, queue, stepinfo);
+  if (sw.err && lane_id() == 0) atomicOr(&out.counters[1], sw.err);
 }
 
 // fold the planes of one level-1 slot / level-2 slot into its running counts and zero them
@@ -763,8 +881,8 @@ __device__ __forceinline__ uint32_t key_ordinal(const Acc& A, uint32_t rs)
 }
 
 __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchOut& out, const Acc& A, WaveState& ws,
-                                                lds_u32* lo, uint32_t lo_words, uint32_t read, uint32_t onmers,
-                                                uint32_t filt0, uint32_t filt1, uint32_t dbg)
+                                                lds_u32* lo, uint32_t lo_words, uint32_t read, uint32_t filt0,
+                                                uint32_t filt1, uint32_t dbg)
 {
   const uint32_t lane = lane_id();
   const uint64_t lt = (1ull << lane) - 1ull;
@@ -919,9 +1037,6 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
       if (lane == 0) {
         out.rd_off[read] = rbase == 0xFFFFFFFFu ? 0 : rbase;
         out.rd_cnt[read] = rbase == 0xFFFFFFFFu ? 0 : nrec;
-        out.rd_onmers[read] = onmers;
-        out.rd_filt[2 * read] = filt0;
-        out.rd_filt[2 * read + 1] = filt1;
       }
       if (nrec && rbase != 0xFFFFFFFFu) {
         for (uint32_t t0 = 0; t0 < nrec; t0 += 64) {
@@ -943,36 +1058,48 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
   } else if (lane == 0) {
     out.rd_off[read] = 0;
     out.rd_cnt[read] = 0;
-    out.rd_onmers[read] = onmers;
-    out.rd_filt[2 * read] = filt0;
-    out.rd_filt[2 * read + 1] = filt1;
   }
   WAVE_SYNC();
   return fits;
 }
 
 // ---------------------------------------------------------------------------
-// One read.
+// Kernel 2: accumulate.  One wave per read: the read's items (colour, tag) are expanded through the
+// colour DAG to leaf events, the events are reduced to per-(leaf, strand) histograms and the
+// records that pass the hdist_filt test are written out.
 // ---------------------------------------------------------------------------
-template <int LOG_G, int CPL, bool SL, bool TAP>
+// fold this segment's planes into running counts (positions of different segments are distinct,
+// so histograms add)
+__device__ __forceinline__ void segment_fold(const Acc& A, WaveState& ws, bool& l2_any)
+{
+  WAVE_SYNC();
+  if (A.keys[lane_id()]) fold_l1(A, lane_id()); // kLdsSlots == 64: lane t owns slot t
+  l2_any = __ballot(ws.l2) != 0;
+  if (l2_any) {
+    const uint32_t n2 = l2_build_list(A);
+    for (uint32_t t = lane_id(); t < n2; t += 64) fold_l2(A, A.g_list[t]);
+  }
+  __syncthreads();
+}
+
+template <bool SL>
 __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams& P, const BatchIn& in,
                                              const BatchOut& out, uint32_t read, const Acc& A, WaveState& ws,
-                                             const ProbeList& pl, lds_u32* hist_tbl, uint32_t hist_words)
+                                             lds_u32* hist_tbl, uint32_t hist_words)
 {
   const uint32_t lane = lane_id();
   const uint64_t lt = (1ull << lane) - 1ull;
-  const uint64_t off0 = in.offsets[read], off1 = in.offsets[read + 1];
-  const uint8_t* seq = in.bases + off0;
-  const uint64_t len = off1 - off0;
+  const uint64_t len = in.offsets[read + 1] - in.offsets[read];
   const uint32_t k = ix.k;
   const uint64_t nkm = len >= k ? len - k + 1 : 0; // enmers (src/query.cpp:42)
-  uint32_t onmers = 0;
-  uint32_t filt0 = 0xFFFFFFFFu, filt1 = 0xFFFFFFFFu;
+  const uint32_t nit = out.rd_it_cnt[read];
+  const uint2* items = out.items + out.rd_it_off[read];
+  const uint32_t onmers = out.rd_onmers[read];
+  const uint32_t filt0 = out.rd_filt[2 * read], filt1 = out.rd_filt[2 * read + 1];
   bool l2_any = false; // wave-uniform: some key of this read lives in level 2
-  ws.read = read;
   ws.evmode = nkm <= (uint64_t)kSegPos && !(P.dbg & 8u); // single segment: event mode
-  // A read is processed once; only if its events do not fit (buffer or histogram table) is it
-  // processed a second time with the plane tables.
+  // A read is processed once; only if its events do not fit (buffer or tables) is it processed a
+  // second time with the plane tables.
   for (;;) {
   if (ws.evmode) {
     ws.dirty = true;
@@ -983,76 +1110,35 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
     WAVE_SYNC();
     ws.dirty = false;
   }
-  onmers = 0;
-  filt0 = 0xFFFFFFFFu, filt1 = 0xFFFFFFFFu;
   ws.top = 0;
   ws.l2 = false;
   ws.nev = 0;
   ws.ev_full = false;
-  for (uint64_t base0 = 0; base0 < nkm; base0 += kSegPos) {
-    const uint32_t npos_seg = (uint32_t)min((uint64_t)kSegPos, nkm - base0);
-    ws.base0 = (uint32_t)base0;
-    SegBits sb;
-    load_segment(seq, len, base0, sb);
-    uint32_t nv = 0;
-    Cand cur = fetch_group<SL>(ix, sb, 0, npos_seg, nv);
-    onmers += nv;
-    const int ngroups = npos_seg > 64 ? 2 : 1;
-    for (int pp = 0; pp < ngroups; ++pp) {
-      // descriptors of the NEXT group are requested before this group is scanned
-      Cand nxt = cur;
-      if (pp + 1 < ngroups) {
-        nxt = fetch_group<SL>(ix, sb, pp + 1, npos_seg, nv);
-        onmers += nv;
-      }
-      // ---- compact the non-empty probes of this group into the LDS list
-      const bool a0 = (cur.b0 & 0xFFFFFFu) != 0, a1 = (cur.b1 & 0xFFFFFFu) != 0;
-      const uint64_t m0 = __ballot(a0), m1 = __ballot(a1);
-      const uint32_t n0 = __popcll(m0), nact = n0 + __popcll(m1);
-      if (a0) {
-        uint32_t i = __popcll(m0 & lt);
-        pl.bkt[i] = cur.b0;
-        pl.q[i] = cur.q0;
-        pl.tag[i] = (64u * pp + lane) | (cur.lib0 << 8);
-      }
-      if (a1) {
-        uint32_t i = n0 + __popcll(m1 & lt);
-        pl.bkt[i] = cur.b1;
-        pl.q[i] = cur.q1;
-        pl.tag[i] = (64u * pp + lane) | (1u << 7) | (cur.lib1 << 8);
-      }
-      WAVE_SYNC();
-      if (!(P.dbg & 4u)) scan_list<LOG_G, CPL, SL, TAP>(ix, P, out, A, ws, pl, nact, filt0, filt1);
-      WAVE_SYNC();
-      cur = nxt;
+  uint32_t cur_seg = 0;
+  for (uint32_t t0 = 0; t0 < ((P.dbg & 2u) ? 0u : nit); t0 += 64) {
+    const uint32_t i = t0 + lane;
+    const bool valid = i < nit;
+    uint2 it = make_uint2(0, 0);
+    if (valid) it = items[i];
+    const uint32_t seg = it.y >> 17;
+    for (;;) { // the items of a tile are in segment order; more than one segment only for long reads
+      if (ws.top > (uint32_t)(kStackUse - 128)) expand_all<SL>(ix, A, ws);
+      expand_step<SL>(ix, A, ws, valid && seg == cur_seg, it.x, it.y & 0x1FFFFu);
+      const uint64_t later = __ballot(valid && seg > cur_seg);
+      if (later == 0) break;
+      expand_all<SL>(ix, A, ws);
+      segment_fold(A, ws, l2_any);
+      cur_seg = __shfl(seg, __ffsll((long long)later) - 1);
     }
-    if (P.dbg & 2u) ws.top = 0;
-    expand_all<SL, TAP>(ix, out, A, ws);
-    if (ws.evmode) break; // single segment, nothing to fold: finalize_events does the rest
-    // ---- fold this segment's planes into running counts (positions of different
-    //      segments are distinct, so histograms add)
-    WAVE_SYNC();
-    if (A.keys[lane]) fold_l1(A, lane); // kLdsSlots == 64: lane t owns slot t
-    l2_any = __ballot(ws.l2) != 0;
-    if (l2_any) {
-      uint32_t n2 = l2_build_list(A);
-      for (uint32_t t = lane; t < n2; t += 64) fold_l2(A, A.g_list[t]);
-    }
-    __syncthreads();
   }
-
-  // ---- per-strand hdist_filt = min hd over kept table entries (src/query.cpp:366-368)
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    filt0 = min(filt0, (uint32_t)__shfl_xor(filt0, d));
-    filt1 = min(filt1, (uint32_t)__shfl_xor(filt1, d));
-  }
+  expand_all<SL>(ix, A, ws);
+  if (!ws.evmode) segment_fold(A, ws, l2_any);
   if (ws.err && lane == 0) atomicOr(&out.counters[1], ws.err);
   ws.err = 0;
   if (!ws.evmode) break;
   if (P.dbg & 16u) ws.nev = 0, ws.ev_full = false;
   if ((P.dbg & 32u) && ws.ev_full) ws.nev = 0, ws.ev_full = false;
-  if (!ws.ev_full && finalize_events(ix, out, A, ws, hist_tbl, hist_words, read, onmers, filt0, filt1, P.dbg)) return;
+  if (!ws.ev_full && finalize_events(ix, out, A, ws, hist_tbl, hist_words, read, filt0, filt1, P.dbg)) return;
   ws.evmode = false; // does not fit: redo the read with the plane tables
   } // redo loop
   // records that pass `hdist_min <= 2*hdist_filt+1` (src/query.cpp:101-106,119), ordered by key so
@@ -1069,9 +1155,6 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
     if (lane == 0) {
       out.rd_off[read] = rbase == 0xFFFFFFFFu ? 0 : rbase;
       out.rd_cnt[read] = rbase == 0xFFFFFFFFu ? 0 : nrec;
-      out.rd_onmers[read] = onmers;
-      out.rd_filt[2 * read] = filt0;
-      out.rd_filt[2 * read + 1] = filt1;
     }
     uint32_t rank = 0; // number of passing keys smaller than mine
     while (okm) {
@@ -1128,9 +1211,6 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   if (lane == 0) {
     out.rd_off[read] = rbase == 0xFFFFFFFFu ? 0 : rbase;
     out.rd_cnt[read] = rbase == 0xFFFFFFFFu ? 0 : nrec;
-    out.rd_onmers[read] = onmers;
-    out.rd_filt[2 * read] = filt0;
-    out.rd_filt[2 * read + 1] = filt1;
   }
   uint32_t run = 0;
   for (uint32_t t0 = 0; t0 < n2; t0 += 64) {
@@ -1157,8 +1237,8 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   __syncthreads();
 }
 
-template <int LOG_G, int CPL, bool SL, bool TAP>
-__global__ __launch_bounds__(kWave, 4) void kr_probe_kernel_t(DevIndex ix, DevParams P, BatchIn in, BatchOut out)
+template <bool SL>
+__global__ __launch_bounds__(kWave, 4) void kr_acc_kernel_t(DevIndex ix, DevParams P, BatchIn in, BatchOut out)
 {
   // One carve of dynamic LDS (base is 16-byte aligned: no static __shared__ in front):
   //   stack | probe list | level-1 table (keys, planes, counts) | level-2 bitmap
@@ -1199,8 +1279,6 @@ __global__ __launch_bounds__(kWave, 4) void kr_probe_kernel_t(DevIndex ix, DevPa
   ws.top = 0;
   ws.l2 = false;
   ws.err = 0;
-  ws.read = 0;
-  ws.base0 = 0;
   ws.rec_next = 0;
   ws.rec_end = 0;
   ws.n_l2 = 0;
@@ -1217,8 +1295,7 @@ __global__ __launch_bounds__(kWave, 4) void kr_probe_kernel_t(DevIndex ix, DevPa
   ws.gev_cap = out.ev_spill;
   ws.gtab_cap = out.tab_spill;
   ws.gkt_cap = out.kt_spill;
-  ProbeList pl{s_bkt, s_q, s_tag};
-  for (uint32_t r = blockIdx.x; r < in.nreads; r += gridDim.x) process_read<LOG_G, CPL, SL, TAP>(ix, P, in, out, r, A, ws, pl, (lds_u32*)s_base, (kStackCap * 8 + kListCap * 16) / 4 + kLdsSlots);
+  for (uint32_t r = blockIdx.x; r < in.nreads; r += gridDim.x) process_read<SL>(ix, P, in, out, r, A, ws, (lds_u32*)s_base, (kStackCap * 8 + kListCap * 16) / 4 + kLdsSlots);
   if (ws.n_l2 && lane_id() == 0) atomicAdd(&out.counters[2], ws.n_l2);
   if (ws.n_rec && lane_id() == 0) atomicAdd(&out.counters[4], ws.n_rec);
 }
@@ -1704,6 +1781,7 @@ uint32_t probe_lds_bytes(uint32_t np, uint32_t bm_words)
 {
   uint32_t b = kStackCap * 8 + kListCap * 8 + 2 * kListCap * 4;
   b += kLdsSlots * 4 + kLdsSlots * np * kPlaneWords * 4 + kLdsSlots * np * 4 + bm_words * 4 + bm_words; // + u16 prefix per 2 words
+  if (getenv("KR_DEBUG_LDS_PAD")) b += (uint32_t)atoi(getenv("KR_DEBUG_LDS_PAD")); // occupancy experiments
   return (b + 15u) & ~15u;
 }
 
@@ -2041,6 +2119,7 @@ struct kr_stream {
   uint64_t h_rec_cap = 0; // pinned record buffers grow on demand in kr_batch_collect
   bool submitted = false, waited = false;
   uint32_t nreads = 0, flags = 0, nrecs = 0;
+  uint32_t scan_blocks = 0;
   uint64_t nhits = 0;
   BatchIn in;
 };
@@ -2075,6 +2154,7 @@ int check_errflags(uint32_t e)
   if (e & kErrStack) return kr::fail(KR_ERR_CAPACITY, "colour work stack overflow (colour DAG deeper than supported)");
   if (e & kErrTable) return kr::fail(KR_ERR_CAPACITY, "global accumulator table overflow");
   if (e & kErrHitCap) return kr::fail(KR_ERR_CAPACITY, "hit tap buffer overflow");
+  if (e & kErrItemCap) return kr::fail(KR_ERR_CAPACITY, "hit list overflow (more than 256 table hits per read on average): submit fewer reads per batch");
   return KR_OK;
 }
 
@@ -2139,6 +2219,12 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   SA(o.rec_sel, s->rec_cap);
   o.rec_cap = s->rec_cap;
   o.hit_cap = s->hit_cap;
+  // item list between the two kernels: 256 hits per read on average, plus one partly used chunk per scan wave
+  s->scan_blocks = (uint32_t)prop.multiProcessorCount * (4u * KR_SCAN_WPE / kScanWaves);
+  o.item_cap = (uint32_t)std::min<uint64_t>((uint64_t)max_reads * 256u + (uint64_t)s->scan_blocks * kScanWaves * 2u * kItemChunk, 1ull << 31);
+  SA(o.items, o.item_cap);
+  SA(o.rd_it_off, max_reads);
+  SA(o.rd_it_cnt, max_reads);
   o.nslots2 = nslots2;
   o.ev_spill = kEvSpill;
   o.tab_spill = std::min<uint32_t>(nslots2, 4096u);
@@ -2220,14 +2306,14 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
     }
   }
   {
-    const uint32_t lds = probe_lds_bytes(s->dp.np, s->out.bm_words);
     const bool tap = (flags & KR_TAP_HITS) != 0;
-#define KR_LAUNCH2(LG, CP, SLV)                                                                                            \
-  do {                                                                                                                 \
-    if (tap)                                                                                                           \
-      hipLaunchKernelGGL((kr_probe_kernel_t<LG, CP, SLV, true>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out); \
-    else                                                                                                               \
-      hipLaunchKernelGGL((kr_probe_kernel_t<LG, CP, SLV, false>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out); \
+    const uint32_t sgrid = std::min<uint32_t>((nreads + kScanWaves - 1) / kScanWaves, s->scan_blocks);
+#define KR_LAUNCH2(LG, CP, SLV)                                                                                              \
+  do {                                                                                                                   \
+    if (tap)                                                                                                             \
+      hipLaunchKernelGGL((kr_scan_kernel_t<LG, CP, SLV, true>), dim3(sgrid), dim3(kScanWaves* kWave), 0, st, dix, s->dp, s->in, s->out); \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((kr_scan_kernel_t<LG, CP, SLV, false>), dim3(sgrid), dim3(kScanWaves* kWave), 0, st, dix, s->dp, s->in, s->out); \
   } while (0)
 #define KR_LAUNCH(LG, CP)          \
   do {                             \
@@ -2245,6 +2331,11 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
 #undef KR_LAUNCH2
 #undef KR_LAUNCH
     HIP_TRY(hipEventRecord(s->ev[2], st));
+    const uint32_t lds = probe_lds_bytes(s->dp.np, s->out.bm_words);
+    if (single)
+      hipLaunchKernelGGL(kr_acc_kernel_t<true>, dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);
+    else
+      hipLaunchKernelGGL(kr_acc_kernel_t<false>, dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);
   }
   HIP_TRY(hipEventRecord(s->ev[3], st));
   if (s->llh.th == 4)
@@ -2374,8 +2465,8 @@ int kr_batch_timing(kr_stream* s, kr_timing* t)
   if (!s || !t || !s->waited) return kr::fail(KR_ERR_STATE, "kr_batch_timing: wait for a batch first");
   memset(t, 0, sizeof(*t));
   HIP_TRY(hipEventElapsedTime(&t->ms_h2d, s->ev[0], s->ev[1]));
-  HIP_TRY(hipEventElapsedTime(&t->ms_probe, s->ev[1], s->ev[2]));
-  HIP_TRY(hipEventElapsedTime(&t->ms_overflow, s->ev[2], s->ev[3]));
+  HIP_TRY(hipEventElapsedTime(&t->ms_scan, s->ev[1], s->ev[2]));
+  HIP_TRY(hipEventElapsedTime(&t->ms_acc, s->ev[2], s->ev[3]));
   HIP_TRY(hipEventElapsedTime(&t->ms_llh, s->ev[3], s->ev[4]));
   HIP_TRY(hipEventElapsedTime(&t->ms_total, s->ev[1], s->ev[4]));
   t->overflow_reads = s->h_counters[2];

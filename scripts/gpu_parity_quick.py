@@ -37,7 +37,7 @@ st = dx.stream(max_reads=nreads, max_bases=len(b))
 st.submit(b, o, capi.KR_TAP_ACCS | capi.KR_TAP_HITS)
 res = st.collect()
 tm = st.timing()
-print('gpu ms probe', tm.ms_probe, 'llh', tm.ms_llh, 'ovf reads', tm.overflow_reads, 'nrecs', res.nrecs, 'nrows', res.nrows)
+print('gpu ms scan', tm.ms_scan, 'acc', tm.ms_acc, 'llh', tm.ms_llh, 'ovf reads', tm.overflow_reads, 'nrecs', res.nrecs, 'nrows', res.nrows)
 # hits
 gh = st.hits()
 a = sorted(zip(gh['read'].tolist(), gh['strand'].tolist(), gh['kpos'].tolist(), gh['cmer_index'].tolist(), gh['hd'].tolist()))

@@ -42,7 +42,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     lines.append(f"\n== {sub}: per-dispatch counter averages ==")
     for k_, cs in acc.items():
-        if "probe" not in k_ and "llh" not in k_ and "select" not in k_:
+        if "kr_scan" not in k_ and "kr_acc" not in k_ and "llh" not in k_ and "select" not in k_:
             continue
         for c, v in cs.items():
             lines.append(f"{k_[:90]}, {c}, n={len(v)}, avg={sum(v)/len(v):.6g}, max={max(v):.6g}")
