@@ -55,8 +55,8 @@ constexpr int kWave = 64;
 constexpr int kSegPos = 128;      // k-mer positions per segment = 4 plane words
 constexpr int kPlaneWords = kSegPos / 32;
 constexpr int kMaxLibs = 16;
-constexpr int kStackCap = 256;    // colour work stack (items of 8 B) ...
-constexpr int kStackUse = kStackCap - 32; // ... whose last 32 slots (64 words) hold the scan's hit-chunk queue
+constexpr int kStackCap = 256;    // colour work stack (items of 8 B)
+constexpr int kStackUse = kStackCap;
 constexpr int kLdsSlots = 64;     // level-1 (LDS) accumulator slots per wave: lane t owns slot t in the epilogue
 constexpr int kLdsProbeMax = 8;   // bounded probe sequence of the level-1 table
 constexpr int kMaxPlanes = KR_MAX_HDIST_TH + 1;
@@ -101,7 +101,7 @@ struct DevParams {
 // Everything the kernels write for one batch.
 struct BatchOut {
   uint32_t* counters;    // [0] record slots handed out  [1] error flags  [2] reads that used level 2  [3] nhits(tap)  [4] records
-                         // [5] LLH chunk cursor  [6] item slots handed out
+                         // [5] LLH chunk cursor  [6] item slots handed out  [7] scan read cursor  [8] accumulate read cursor
   uint32_t* rd_off;
   uint32_t* rd_cnt;
   uint32_t* rd_onmers;
@@ -515,6 +515,7 @@ struct ScanWave {
   uint32_t filt0, filt1;    // per-lane running min hd per strand (hdist_filt, src/query.cpp:366-368)
 };
 constexpr uint32_t kItemChunk = 2048;
+constexpr uint32_t kReadChunk = 8; // reads a wave takes per visit to the shared read cursor
 
 // Make room for n more items directly behind the current read's items (wave-uniform).
 __device__ __forceinline__ bool item_reserve(const BatchOut& out, ScanWave& sw, uint32_t n)
@@ -753,8 +754,15 @@ __global__ __launch_bounds__(kScanWaves* kWave, KR_SCAN_WPE) void kr_scan_kernel
   sw.it_next = sw.it_end = sw.rd_start = 0;
   sw.err = 0;
   sw.filt0 = sw.filt1 = 0xFFFFFFFFu;
-  const uint32_t nw = gridDim.x * kScanWaves;
-  for (uint32_t r = blockIdx.x * kScanWaves + w; r < in.nreads; r += nw) scan_read<LOG_G, CPL, SL, TAP>(ix, P, in, out, r, sw, pl, queue, stepinfo);
+  // reads are handed out in small chunks (heavy reads do not pile up on one wave, no tail)
+  for (;;) {
+    uint32_t r0 = 0;
+    if (lane_id() == 0) r0 = atomicAdd(&out.counters[7], kReadChunk);
+    r0 = __shfl(r0, 0);
+    if (r0 >= in.nreads) break;
+    const uint32_t r1 = min(r0 + kReadChunk, in.nreads);
+    for (uint32_t r = r0; r < r1; ++r) scan_read<LOG_G, CPL, SL, TAP>(ix, P, in, out, r, sw, pl, queue, stepinfo);
+  }
   if (sw.err && lane_id() == 0) atomicOr(&out.counters[1], sw.err);
 }
 
@@ -923,13 +931,13 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
       nkeys += __shfl(inc, 63);
     }
     WAVE_SYNC();
-    // keytab[nkeys] at the top of the low region if that leaves room for 64 table entries, else in
-    // global scratch (reads with close to a thousand keys)
-    const bool kt_lds = nkeys + 64u * ew <= lo_words;
+    // keytab[nkeys] behind the events if that leaves room for a batch of 8 keys, else in global scratch
+    const uint32_t nev_lds = (min(nev, ws.ev_cap) + 1u) & ~1u;
+    const bool kt_lds = nev_lds + nkeys + 8u * kw <= ws.ev_words;
     fits = kt_lds || nkeys <= ws.gkt_cap;
-    lds_u32* keytab = lo + lo_words - (kt_lds ? nkeys : 0u);
+    lds_u32* keytab = e + nev_lds;
     uint32_t* gkt = gtab + (uint64_t)ws.gtab_cap * ew;
-    const uint32_t tab_cap = (lo_words - (kt_lds ? nkeys : 0u)) / ew;
+    const uint32_t tab_cap = lo_words / ew;
     // ---- 2. ordinals into the events, keys into keytab; hd levels present
     uint32_t lv = 0;
     if (fits)
@@ -966,9 +974,9 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
     }
     if (dbg & 64u) nkeys = 0;
     // ---- 3. batches of KB ordinals
-    const uint32_t nev_lds = (min(nev, ws.ev_cap) + 1u) & ~1u;
-    lds_u32* bt = e + nev_lds; // [KB][kw]
-    const uint32_t KB = (ws.ev_words - nev_lds) / kw;
+    const uint32_t bt_off = nev_lds + (kt_lds ? ((nkeys + 1u) & ~1u) : 0u);
+    lds_u32* bt = e + bt_off; // [KB][kw]
+    const uint32_t KB = (ws.ev_words - bt_off) / kw;
     for (uint32_t k0 = 0; k0 < nkeys; k0 += KB) {
       const uint32_t kn = min(KB, nkeys - k0);
       for (uint32_t i = lane; i < kn * kw; i += 64) bt[i] = 0;
@@ -1241,14 +1249,11 @@ template <bool SL>
 __global__ __launch_bounds__(kWave, 4) void kr_acc_kernel_t(DevIndex ix, DevParams P, BatchIn in, BatchOut out)
 {
   // One carve of dynamic LDS (base is 16-byte aligned: no static __shared__ in front):
-  //   stack | probe list | level-1 table (keys, planes, counts) | level-2 bitmap
+  //   stack | level-1 table (keys, planes, counts) | level-2 bitmap | ordinal prefix
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   KR_LDS uint8_t* s_base = (KR_LDS uint8_t*)s_dyn;
   lds_u64* s_stack = (lds_u64*)s_base;
-  lds_u64* s_bkt = (lds_u64*)(s_base + kStackCap * 8);
-  lds_u32* s_q = (lds_u32*)(s_base + kStackCap * 8 + kListCap * 8);
-  lds_u32* s_tag = s_q + kListCap;
-  lds_u32* s_tbl = s_tag + kListCap;
+  lds_u32* s_tbl = (lds_u32*)(s_base + kStackCap * 8);
 
   Acc A;
   A.np = P.np;
@@ -1295,7 +1300,14 @@ __global__ __launch_bounds__(kWave, 4) void kr_acc_kernel_t(DevIndex ix, DevPara
   ws.gev_cap = out.ev_spill;
   ws.gtab_cap = out.tab_spill;
   ws.gkt_cap = out.kt_spill;
-  for (uint32_t r = blockIdx.x; r < in.nreads; r += gridDim.x) process_read<SL>(ix, P, in, out, r, A, ws, (lds_u32*)s_base, (kStackCap * 8 + kListCap * 16) / 4 + kLdsSlots);
+  for (;;) {
+    uint32_t r0 = 0;
+    if (lane_id() == 0) r0 = atomicAdd(&out.counters[8], kReadChunk);
+    r0 = __shfl(r0, 0);
+    if (r0 >= in.nreads) break;
+    const uint32_t r1 = min(r0 + kReadChunk, in.nreads);
+    for (uint32_t r = r0; r < r1; ++r) process_read<SL>(ix, P, in, out, r, A, ws, (lds_u32*)s_base, kStackCap * 2 + kLdsSlots);
+  }
   if (ws.n_l2 && lane_id() == 0) atomicAdd(&out.counters[2], ws.n_l2);
   if (ws.n_rec && lane_id() == 0) atomicAdd(&out.counters[4], ws.n_rec);
 }
@@ -1496,7 +1508,13 @@ __device__ __forceinline__ void load_problem(const LlhConst& C, const uint32_t* 
 // kLlhRefill lanes are idle, the idle lanes take the next records of the wave's current chunk (chunks of
 // kLlhChunk records are handed out through counters[5]).  Every step evaluates the objective once for
 // all busy lanes.
-constexpr uint32_t kLlhChunkMax = 2048, kLlhRefill = 8;
+#ifndef KR_LLH_REFILL
+#define KR_LLH_REFILL 8
+#endif
+#ifndef KR_LLH_WPE
+#define KR_LLH_WPE 4
+#endif
+constexpr uint32_t kLlhChunkMax = 2048, kLlhRefill = KR_LLH_REFILL;
 template <int NPT>
 __device__ __forceinline__ void llh_records(const LlhConst& C, const LlhTables& T, const DevIndex& ix, const BatchOut& out)
 {
@@ -1559,7 +1577,7 @@ __device__ __forceinline__ void llh_records(const LlhConst& C, const LlhTables& 
 
 // NPT = 5: --hdist-th default, histogram in registers; NPT = 0: any threshold
 template <int NPT>
-__global__ __launch_bounds__(256) void kr_llh_kernel(LlhConst C, DevIndex ix, BatchOut out)
+__global__ __launch_bounds__(256, KR_LLH_WPE) void kr_llh_kernel(LlhConst C, DevIndex ix, BatchOut out)
 {
   __shared__ double s_bk[32], s_hnk[kMaxPlanes];
   LlhTables T{(lds_f64*)s_bk, (lds_f64*)s_hnk};
@@ -1779,7 +1797,7 @@ __global__ void kr_relayout_inc(const uint64_t* inc, uint32_t nrows, uint64_t* b
 // dynamic LDS bytes of the probe kernel: stack + probe list + ntouched (+ table)
 uint32_t probe_lds_bytes(uint32_t np, uint32_t bm_words)
 {
-  uint32_t b = kStackCap * 8 + kListCap * 8 + 2 * kListCap * 4;
+  uint32_t b = kStackCap * 8;
   b += kLdsSlots * 4 + kLdsSlots * np * kPlaneWords * 4 + kLdsSlots * np * 4 + bm_words * 4 + bm_words; // + u16 prefix per 2 words
   if (getenv("KR_DEBUG_LDS_PAD")) b += (uint32_t)atoi(getenv("KR_DEBUG_LDS_PAD")); // occupancy experiments
   return (b + 15u) & ~15u;
@@ -2183,7 +2201,7 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
   // resident waves per CU: LDS-limited (160 KiB per CU), VGPR-limited to 4 waves per SIMD
   const uint32_t nslots2 = std::max<uint32_t>(2u, 2u * ix->dix.nleaves), bm_words = ((nslots2 + 63) / 64) * 2;
-  uint32_t per_cu = std::min<uint32_t>(16u, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words));
+  uint32_t per_cu = std::min<uint32_t>(20u, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words));
   s->nwaves = (uint32_t)prop.multiProcessorCount * std::max<uint32_t>(1u, per_cu);
   // default record capacity: up to 2 * leaves per read, at most 16 per read on average
   uint64_t per_read = std::min<uint64_t>(16, std::max<uint64_t>(8, (uint64_t)ix->dix.tree_nnodes + 1));
@@ -2204,7 +2222,7 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   if ((rc = halloc(s.get(), &ptr, (n)))) { kr_stream_destroy(s.release()); return rc; }
   SA(s->d_bases, max_bases + 256);
   SA(s->d_offsets, (uint64_t)max_reads + 1);
-  SA(o.counters, 8);
+  SA(o.counters, 16);
   SA(o.rd_off, max_reads);
   SA(o.rd_cnt, max_reads);
   SA(o.rd_onmers, max_reads);
@@ -2220,7 +2238,7 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   o.rec_cap = s->rec_cap;
   o.hit_cap = s->hit_cap;
   // item list between the two kernels: 256 hits per read on average, plus one partly used chunk per scan wave
-  s->scan_blocks = (uint32_t)prop.multiProcessorCount * (4u * KR_SCAN_WPE / kScanWaves);
+  s->scan_blocks = (uint32_t)prop.multiProcessorCount * (4u * KR_SCAN_WPE / kScanWaves); // resident by construction (launch bounds)
   o.item_cap = (uint32_t)std::min<uint64_t>((uint64_t)max_reads * 256u + (uint64_t)s->scan_blocks * kScanWaves * 2u * kItemChunk, 1ull << 31);
   SA(o.items, o.item_cap);
   SA(o.rd_it_off, max_reads);
@@ -2291,7 +2309,7 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
     s->in.offsets = s->d_offsets;
   }
   s->in.nreads = nreads;
-  HIP_TRY(hipMemsetAsync(s->out.counters, 0, 32, st));
+  HIP_TRY(hipMemsetAsync(s->out.counters, 0, 64, st));
   HIP_TRY(hipMemsetAsync(s->out.rec_key, 0, (uint64_t)s->rec_cap * 4, st));
   HIP_TRY(hipMemsetAsync(s->out.rec_sel, 0, (uint64_t)s->rec_cap, st));
   HIP_TRY(hipEventRecord(s->ev[1], st));

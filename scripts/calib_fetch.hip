@@ -22,6 +22,23 @@ __global__ void gather128(const uint4* buf, const uint32_t* blk, uint64_t nblock
   }
   if (acc == 0x12345678u) sink[0] = acc;
 }
+// The scan kernel's shape: 4 lanes x dwordx4 = one 64-byte piece; a wave instruction reads 16 random
+// pieces; `nj` such instructions read the following 64-byte pieces of the same 16 buckets.
+__global__ void gather64(const uint4* buf, const uint32_t* blk, uint64_t nblocks, uint32_t nj, uint32_t* sink)
+{
+  uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 2;
+  uint32_t sub = threadIdx.x & 3;
+  uint32_t acc = 0;
+  for (; g < nblocks; g += ((uint64_t)gridDim.x * blockDim.x) >> 2) {
+    if (blk[g] & 1u) continue;                        // even blocks only: each owns 256 bytes
+    const uint4* b = buf + (uint64_t)blk[g] * 8 + sub; // random 256-byte regions, each used once
+    uint4 v0 = b[0], v1 = make_uint4(0, 0, 0, 0), v2 = make_uint4(0, 0, 0, 0);
+    if (nj > 1) v1 = b[4];
+    if (nj > 2) v2 = b[8];
+    acc ^= v0.x ^ v0.y ^ v0.z ^ v0.w ^ v1.x ^ v1.w ^ v2.x ^ v2.w;
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
 __global__ void gather8(const uint64_t* buf, const uint32_t* idx, uint64_t n, uint32_t* sink)
 {
   uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -49,7 +66,11 @@ int main()
   hipDeviceSynchronize();
   for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gather128, dim3(8192), dim3(256), 0, 0, buf, blk, nblocks, sink);
   for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gather8, dim3(8192), dim3(256), 0, 0, (const uint64_t*)buf, blk, nblocks, sink);
+  // 2^24 random 256-byte slots of the same buffer: 64 / 128 / 192 bytes of each
+  for (uint32_t nj = 1; nj <= 3; ++nj)
+    hipLaunchKernelGGL(gather64, dim3(8192), dim3(256), 0, 0, buf, blk, nblocks, nj, sink);
   hipDeviceSynchronize();
+  printf("gather64 x nj: known bytes per launch: nj * 64 * %llu (+ index)\n", (unsigned long long)(nblocks / 2));
   printf("gather128 known bytes per launch: %llu (+ %llu index bytes)\n", (unsigned long long)(nblocks * 128), (unsigned long long)(nblocks * 4));
   printf("gather8   known useful bytes per launch: %llu, lines touched %llu x 128 B (+ index)\n", (unsigned long long)(nblocks * 8), (unsigned long long)nblocks);
   return 0;
