@@ -6,7 +6,7 @@
 // (src/krepp.cpp:48-64, src/phytree.cpp:421-473).
 //
 // Split of work: the GPU has already produced, per read, one record per (leaf, strand) with its
-// histogram, distance and likelihood (kr_probe/llh/select kernels).  Here the host walks each leaf's
+// histogram, distance and likelihood (kr_scan/acc/llh/select kernels).  Here the host walks each leaf's
 // ancestors accumulating weighted histograms (a few hundred adds per read), then ALL likelihood work
 // of the batch — Brent on every candidate internal node, and the chi-square evaluation of every
 // candidate against the read's closest leaf — goes back to the GPU as two kr_llh_batch launches.
