@@ -102,6 +102,7 @@ struct DevParams {
 struct BatchOut {
   uint32_t* counters;    // [0] record slots handed out  [1] error flags  [2] reads that used level 2  [3] nhits(tap)  [4] records
                          // [5] LLH chunk cursor  [6] item slots handed out  [7] scan read cursor  [8] accumulate read cursor
+  uint32_t* cursors;     // read cursors of the scan and the accumulate kernel, [2][kCursors * kCursorStride]
   uint32_t* rd_off;
   uint32_t* rd_cnt;
   uint32_t* rd_onmers;
@@ -118,7 +119,8 @@ struct BatchOut {
   kr_hit* hits;
   uint32_t hit_cap;
   // scan kernel -> accumulate kernel: resolved hits (colour, tag) of every read, contiguous per read
-  uint2* items;          // x = tagged colour id, y = pos(7) | strand<<7 | lib(4)<<8 | hd(5)<<12 | segment(14)<<17
+  uint2* items;          // x = entry index (low 32), y = pos(7) | strand<<7 | lib(4)<<8 | hd(5)<<12 | index high(8)<<17;
+                         // y bit 31: segment marker, x = segment number
   uint32_t item_cap;
   uint32_t* rd_it_off;
   uint32_t* rd_it_cnt;
@@ -152,6 +154,7 @@ __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 typedef KR_LDS uint32_t lds_u32;
 typedef KR_LDS uint64_t lds_u64;
 typedef KR_LDS uint16_t lds_u16;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t lds_cas(lds_u32* p, uint32_t expected, uint32_t desired)
 {
   __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -174,8 +177,13 @@ __device__ __forceinline__ uint32_t lds_ld(lds_u32* p) { return __hip_atomic_loa
 // hd = number of non-LSH positions that differ (popcount_lr32, src/common.hpp:175)
 __device__ __forceinline__ uint32_t hd_lr32(uint32_t a, uint32_t b)
 {
-  uint32_t z = a ^ b;
+  uint32_t z = a ^ b, f;
+#ifdef KR_NO_SDWA
   return __popc((z | (z >> 16)) & 0xFFFFu);
+#endif
+  // (z | z >> 16) & 0xffff in one instruction: OR of the two 16-bit halves, zero-extended (SDWA operand selects)
+  asm("v_or_b32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(f) : "v"(z));
+  return __popc(f);
 }
 
 __device__ __forceinline__ uint32_t hash_key(uint32_t key) { return key * 0x9E3779B1u; }
@@ -286,7 +294,8 @@ __device__ __forceinline__ uint32_t gload(const uint32_t* p) { return __hip_atom
 __device__ __forceinline__ void gstore(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Work-stack item (8 B): lo = tagged colour id, hi = pos(7) | strand(1)<<7 | lib(4)<<8 | hd(5)<<12.
-// The items the scan kernel hands over carry the read's segment number in hi bits 17..30.
+// The items the scan kernel hands over name the table ENTRY instead (index low in lo, high 8 bits in hi
+// bits 17..24); the accumulate kernel fetches the colour.
 __device__ __forceinline__ uint32_t tag_pos(uint32_t t) { return t & 127u; }
 __device__ __forceinline__ uint32_t tag_strand(uint32_t t) { return (t >> 7) & 1u; }
 __device__ __forceinline__ uint32_t tag_lib(uint32_t t) { return (t >> 8) & 15u; }
@@ -513,9 +522,39 @@ struct ScanWave {
   uint32_t rd_start;        // first item of the current read
   uint32_t err;
   uint32_t filt0, filt1;    // per-lane running min hd per strand (hdist_filt, src/query.cpp:366-368)
+  uint32_t cur_seg;         // segment of the read's most recent item (wave-uniform)
 };
 constexpr uint32_t kItemChunk = 2048;
-constexpr uint32_t kReadChunk = 8; // reads a wave takes per visit to the shared read cursor
+constexpr uint32_t kReadChunk = 8; // reads a wave takes per visit to a read cursor
+// Reads are handed out in small chunks (heavy reads do not pile up on one wave, no tail).  One shared
+// cursor would serve only ~90 M atomics/s -- 1.4 ms for a million reads -- so the batch is cut into
+// kCursors ranges with a cursor each (on cache lines of their own); a wave starts on its "home" range
+// and moves on to the next when that is used up.
+constexpr uint32_t kCursors = 32, kCursorStride = 32; // words
+struct ReadCursor {
+  uint32_t* cur;   // [kCursors * kCursorStride]
+  uint32_t nreads, range, c, tried;
+  __device__ __forceinline__ void init(uint32_t* base, uint32_t n, uint32_t home)
+  {
+    cur = base, nreads = n, range = (n + kCursors - 1) / kCursors, c = home % kCursors, tried = 0;
+  }
+  // next chunk [r0, r1); false when every range is used up (wave-uniform)
+  __device__ __forceinline__ bool next(uint32_t& r0, uint32_t& r1)
+  {
+    while (tried < kCursors) {
+      const uint32_t lo = c * range, hi = min(lo + range, nreads);
+      uint32_t o = 0;
+      if (lane_id() == 0) o = atomicAdd(&cur[c * kCursorStride], kReadChunk);
+      o = __shfl(o, 0);
+      if (lo + o < hi) {
+        r0 = lo + o, r1 = min(r0 + kReadChunk, hi);
+        return true;
+      }
+      c = (c + 1) % kCursors, ++tried;
+    }
+    return false;
+  }
+};
 
 // Make room for n more items directly behind the current read's items (wave-uniform).
 __device__ __forceinline__ bool item_reserve(const BatchOut& out, ScanWave& sw, uint32_t n)
@@ -543,7 +582,11 @@ __device__ __forceinline__ bool item_reserve(const BatchOut& out, ScanWave& sw, 
   return true;
 }
 
-// Entries `pend` (4-bit mask) of chunk c of the bucket at e_al matched: fetch their colours, append items.
+// Entries `pend` (4-bit mask) of chunk c of the bucket at e_al matched: append one item per entry.  The item
+// names the entry (its colour id is fetched by the accumulate kernel: this kernel runs at the chip's
+// random-request rate, that one has memory bandwidth to spare).  Reads of more than one segment get a
+// marker item in front of the first item of every later segment.
+constexpr uint32_t kItemMarker = 0x80000000u;
 template <bool SL, bool TAP>
 __device__ __forceinline__ void emit_hits(const DevIndex& ix, const BatchOut& out, ScanWave& sw, uint32_t read, uint32_t base0,
                                           uint32_t tg, uint64_t e_al, uint32_t c, uint32_t pend, uint32_t hds)
@@ -555,14 +598,13 @@ __device__ __forceinline__ void emit_hits(const DevIndex& ix, const BatchOut& ou
     const uint32_t e = has ? (uint32_t)__ffs((int)pend) - 1u : 0u;
     const uint32_t hd = (hds >> (8u * e)) & 31u;
     const uint64_t idx = e_al + 4ull * c + e;
-    uint32_t se = 0;
     if (has) {
-      se = get_lib<SL>(ix, tag_lib(tg)).se[idx];
       if (tag_strand(tg))
         sw.filt1 = min(sw.filt1, hd);
       else
         sw.filt0 = min(sw.filt0, hd);
       if (TAP) {
+        const uint32_t se = get_lib<SL>(ix, tag_lib(tg)).se[idx];
         const uint32_t hix = atomicAdd(&out.counters[3], 1u);
         if (hix < out.hit_cap) {
           kr_hit h;
@@ -579,11 +621,16 @@ __device__ __forceinline__ void emit_hits(const DevIndex& ix, const BatchOut& ou
         }
       }
     }
-    const bool keep = has && (se >> 30) != 0u; // class 0: empty colour / null tree node
-    const uint64_t km = __ballot(keep);
-    if (km != 0 && item_reserve(out, sw, (uint32_t)__popcll(km))) {
-      if (keep) out.items[sw.it_next + __popcll(km & lt)] = make_uint2(se, (tg & 0xFFFu) | (hd << 12) | (seg << 17));
-      sw.it_next += (uint32_t)__popcll(km);
+    const uint64_t hm = __ballot(has);
+    const uint32_t mark = seg != sw.cur_seg ? 1u : 0u; // wave-uniform
+    if (item_reserve(out, sw, (uint32_t)__popcll(hm) + mark)) {
+      if (mark && lane_id() == 0) out.items[sw.it_next] = make_uint2(seg, kItemMarker);
+      sw.it_next += mark;
+      sw.cur_seg = seg;
+      if (has)
+        out.items[sw.it_next + __popcll(hm & lt)] =
+          make_uint2((uint32_t)idx, (tg & 0xFFFu) | (hd << 12) | ((uint32_t)(idx >> 32) << 17));
+      sw.it_next += (uint32_t)__popcll(hm);
     }
     pend &= pend - 1u;
   }
@@ -617,6 +664,8 @@ __device__ __forceinline__ void scan_group(const DevIndex& ix, const DevParams& 
       const uint32_t* enc = get_lib<SL>(ix, SL ? 0u : tag_lib(pl.tag[on ? pi : 0u])).enc + (st & ~3ull);
       for (; step < kBits && __ballot(sub + cb * G < nch) != 0; cb += CPL, step += CPL) {
         if (lane < (uint32_t)CPL) stepinfo[step + lane] = p0 | (((cb + lane) * G) << 8);
+        // (loads stay masked for chunks past the end of the bucket: clamping them onto the last chunk instead
+        //  saves instructions but costs 20 % in run time -- the extra lanes load the texture path)
         uint4 v[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
@@ -625,11 +674,13 @@ __device__ __forceinline__ void scan_group(const DevIndex& ix, const DevParams& 
           if (c < nch) v[j] = *reinterpret_cast<const uint4*>(enc + 4u * c);
         }
         // entries of the neighbouring buckets in the first / last chunk may give false positives, rejected below
+        uint32_t r = 0;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
           const uint32_t m = min(min(hd_lr32(v[j].x, q), hd_lr32(v[j].y, q)), min(hd_lr32(v[j].z, q), hd_lr32(v[j].w, q)));
-          if (m <= P.th && sub + (cb + (uint32_t)j) * G < nch) hitbits |= 1ull << (step + (uint32_t)j);
+          r |= (m <= P.th && sub + (cb + (uint32_t)j) * G < nch) ? (1u << j) : 0u;
         }
+        hitbits |= (uint64_t)r << step;
       }
       if (__ballot(sub + cb * G < nch) == 0) p0 += PPS, cb = 0; // pass finished
     }
@@ -689,6 +740,7 @@ __device__ __forceinline__ void scan_read(const DevIndex& ix, const DevParams& P
   const uint64_t nkm = len >= k ? len - k + 1 : 0; // enmers (src/query.cpp:42)
   uint32_t onmers = 0;
   sw.rd_start = sw.it_next;
+  sw.cur_seg = 0;
   sw.filt0 = 0xFFFFFFFFu, sw.filt1 = 0xFFFFFFFFu;
   for (uint64_t base0 = 0; base0 < nkm; base0 += kSegPos) {
     const uint32_t npos_seg = (uint32_t)min((uint64_t)kSegPos, nkm - base0);
@@ -753,16 +805,13 @@ __global__ __launch_bounds__(kScanWaves* kWave, KR_SCAN_WPE) void kr_scan_kernel
   ScanWave sw;
   sw.it_next = sw.it_end = sw.rd_start = 0;
   sw.err = 0;
+  sw.cur_seg = 0;
   sw.filt0 = sw.filt1 = 0xFFFFFFFFu;
-  // reads are handed out in small chunks (heavy reads do not pile up on one wave, no tail)
-  for (;;) {
-    uint32_t r0 = 0;
-    if (lane_id() == 0) r0 = atomicAdd(&out.counters[7], kReadChunk);
-    r0 = __shfl(r0, 0);
-    if (r0 >= in.nreads) break;
-    const uint32_t r1 = min(r0 + kReadChunk, in.nreads);
+  ReadCursor rc;
+  rc.init(out.cursors, in.nreads, blockIdx.x * kScanWaves + w);
+  uint32_t r0, r1;
+  while (rc.next(r0, r1))
     for (uint32_t r = r0; r < r1; ++r) scan_read<LOG_G, CPL, SL, TAP>(ix, P, in, out, r, sw, pl, queue, stepinfo);
-  }
   if (sw.err && lane_id() == 0) atomicOr(&out.counters[1], sw.err);
 }
 
@@ -881,6 +930,97 @@ __device__ __forceinline__ uint32_t alloc_records(const BatchOut& out, WaveState
 // Returns false if the read does not fit (more keys than keytab holds, more passing keys than the
 // table and its global spill hold): the caller falls back to the plane tables.
 // ---------------------------------------------------------------------------
+// Lanes of a wave that OR bits into the SAME LDS (or L2) word serialise, 10-15 cycles per lane, and
+// events of one key at neighbouring positions -- the common case -- arrive in consecutive lanes.  This
+// combines runs of consecutive lanes with equal `addr` in registers (segmented inclusive OR-scan on DPP:
+// four row shifts, two row broadcasts) so that only the LAST lane of a run issues the atomic.
+// addr of inactive lanes must be unique (e.g. ~lane).  Returns the bits this lane should OR, `tail` says whether it should.
+__device__ __forceinline__ uint32_t seg_or_combine(uint32_t addr, uint32_t bits, bool& tail)
+{
+  const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)~addr, (int)addr, 0x138, 0xF, 0xF, false); // wave_shr:1
+  uint32_t f = prev != addr ? 1u : 0u, v = bits;                                                              // f: a run starts here
+  const uint32_t nf = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)f, 0x130, 0xF, 0xF, false);              // wave_shl:1
+  tail = nf != 0;
+#define KR_SEG_STEP(CTRL, RMASK)                                                                   \
+  {                                                                                                \
+    const uint32_t tv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, RMASK, 0xF, true);  \
+    const uint32_t tf = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, CTRL, RMASK, 0xF, true);  \
+    v = f ? v : (v | tv);                                                                          \
+    f |= tf;                                                                                       \
+  }
+  KR_SEG_STEP(0x111, 0xF) // row_shr:1
+  KR_SEG_STEP(0x112, 0xF) // row_shr:2
+  KR_SEG_STEP(0x114, 0xF) // row_shr:4
+  KR_SEG_STEP(0x118, 0xF) // row_shr:8
+  KR_SEG_STEP(0x142, 0xA) // row_bcast:15 -> rows 1, 3
+  KR_SEG_STEP(0x143, 0xC) // row_bcast:31 -> rows 2, 3
+#undef KR_SEG_STEP
+  return v;
+}
+
+// Batch arrays of the event epilogue live in LDS, or -- for the rare read with more keys than the LDS
+// holds -- in the wave's global scratch (L2): same code, memory operations by pointer type.
+__device__ __forceinline__ void mem_or(lds_u32* p, uint32_t v) { lds_or(p, v); }
+__device__ __forceinline__ void mem_or(uint32_t* p, uint32_t v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t mem_ld(lds_u32* p) { return *p; }
+__device__ __forceinline__ uint32_t mem_ld(uint32_t* p) { return gload(p); }
+__device__ __forceinline__ void mem_st(lds_u32* p, uint32_t v) { *p = v; }
+__device__ __forceinline__ void mem_st(uint32_t* p, uint32_t v) { gstore(p, v); }
+__device__ __forceinline__ void mem_sync(lds_u32*) { WAVE_SYNC(); }
+__device__ __forceinline__ void mem_sync(uint32_t*)
+{
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // this wave's global atomics / stores have landed in L2
+  WAVE_SYNC();
+}
+
+// One pass over the events whose key ordinal lies in [k0, k0 + kn): an event ORs its position bit into
+// plane `hd` of its key (np planes of 128 bits per key; bit `pos >> 2` of word `pos & 3`, so that a run
+// of neighbouring positions spreads over the four words).  The per-position minimum is taken afterwards,
+// by the lane that owns the key: count[hd] = popc(plane[hd] & ~(plane[0] | ... | plane[hd-1])).
+template <typename PT, typename EV>
+__device__ __forceinline__ void plane_pass(PT bt, uint32_t np, uint32_t k0, uint32_t kn, uint32_t nev, EV ev_at)
+{
+  const uint32_t lane = lane_id();
+  for (uint32_t i = lane; i < kn * np * kPlaneWords; i += 64) mem_st(bt + i, 0u);
+  mem_sync(bt);
+  for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
+    const uint32_t i = t0 + lane;
+    if (i < nev) {
+      const uint32_t v = ev_at(t0, i);
+      const uint32_t o = (v >> 12) - k0;
+      if (o < kn) {
+        const uint32_t pos = (v >> 5) & 127u;
+        mem_or(bt + (o * np + (v & 31u)) * kPlaneWords + (pos & 3u), 1u << (pos >> 2));
+      }
+    }
+  }
+  mem_sync(bt);
+}
+// packed 8-bit counters (four hd values per word) of key j of the batch
+__device__ __forceinline__ void plane_counts(lds_u32* bt, uint32_t np, uint32_t j, uint32_t* c)
+{
+  u32x4 seen = {0, 0, 0, 0};
+#pragma unroll
+  for (int x = 0; x < kMaxPlanes; ++x)
+    if ((uint32_t)x < np) {
+      const u32x4 pw = *(KR_LDS u32x4*)(bt + (j * np + x) * kPlaneWords); // ds_read_b128
+      c[x >> 2] += (uint32_t)(__popc(pw.x & ~seen.x) + __popc(pw.y & ~seen.y) + __popc(pw.z & ~seen.z) + __popc(pw.w & ~seen.w)) << (8 * (x & 3));
+      seen |= pw;
+    }
+}
+__device__ __forceinline__ void plane_counts(uint32_t* bt, uint32_t np, uint32_t j, uint32_t* c)
+{
+  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+  for (int x = 0; x < kMaxPlanes; ++x)
+    if ((uint32_t)x < np) {
+      uint32_t* p = bt + (uint64_t)(j * np + x) * kPlaneWords;
+      const uint32_t w0 = gload(p), w1 = gload(p + 1), w2 = gload(p + 2), w3 = gload(p + 3);
+      c[x >> 2] += (uint32_t)(__popc(w0 & ~s0) + __popc(w1 & ~s1) + __popc(w2 & ~s2) + __popc(w3 & ~s3)) << (8 * (x & 3));
+      s0 |= w0, s1 |= w1, s2 |= w2, s3 |= w3;
+    }
+}
+
 __device__ __forceinline__ uint32_t key_ordinal(const Acc& A, uint32_t rs)
 {
   const uint32_t blk = rs >> 6;
@@ -898,7 +1038,7 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
   const uint32_t lim0 = 2u * filt0 + 1u, lim1 = 2u * filt1 + 1u; // u32 wrap keeps "none" = max
   const uint32_t hw = (A.np + 3u) >> 2; // histogram words per key
   const uint32_t ew = hw + 1u;          // table entry: packed counters, key
-  const uint32_t kw = kPlaneWords + hw; // batch words per key: position map, counters
+  const uint32_t kw = A.np * kPlaneWords; // batch words per key: np planes of 128 position bits
   lds_u32* e = ws.ev;
   uint32_t nrec = 0;
   bool fits = true;
@@ -910,10 +1050,11 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
     // ---- 1. mark keys, ordinal prefix per 64-bit block
     for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
       const uint32_t i = t0 + lane;
-      if (i < nev) {
-        const uint32_t rs = ev_at(t0, i) >> 12;
-        lds_or(&A.bitmap[rs >> 5], 1u << (rs & 31u));
-      }
+      const uint32_t rs = i < nev ? ev_at(t0, i) >> 12 : 0u;
+      const uint32_t word = i < nev ? rs >> 5 : ~lane;
+      bool tail;
+      const uint32_t bits = seg_or_combine(word, i < nev ? 1u << (rs & 31u) : 0u, tail);
+      if (i < nev && tail) lds_or(&A.bitmap[word], bits);
     }
     WAVE_SYNC();
     uint32_t nkeys = 0;
@@ -933,12 +1074,12 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
     WAVE_SYNC();
     // keytab[nkeys] behind the events if that leaves room for a batch of 8 keys, else in global scratch
     const uint32_t nev_lds = (min(nev, ws.ev_cap) + 1u) & ~1u;
-    const bool kt_lds = nev_lds + nkeys + 8u * kw <= ws.ev_words;
+    const bool kt_lds = nev_lds + nkeys + 4u + 8u * kw <= ws.ev_words;
     fits = kt_lds || nkeys <= ws.gkt_cap;
     lds_u32* keytab = e + nev_lds;
     uint32_t* gkt = gtab + (uint64_t)ws.gtab_cap * ew;
     const uint32_t tab_cap = lo_words / ew;
-    // ---- 2. ordinals into the events, keys into keytab; hd levels present
+    // ---- 2. ordinals into the events, keys into keytab
     uint32_t lv = 0;
     if (fits)
       for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
@@ -973,30 +1114,24 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
       nkeys = 0;
     }
     if (dbg & 64u) nkeys = 0;
-    // ---- 3. batches of KB ordinals
-    const uint32_t bt_off = nev_lds + (kt_lds ? ((nkeys + 1u) & ~1u) : 0u);
+    // ---- 3. batches of KB ordinals; a read with more than 16 LDS batches of keys runs as ONE batch in the
+    //         wave's global scratch (A.g_planes, all-zero between reads like the plane path needs it):
+    //         L2 atomics are ~10x slower than LDS ones, the batches re-read the events
+    const uint32_t bt_off = (nev_lds + (kt_lds ? nkeys : 0u) + 3u) & ~3u; // 16-byte aligned
     lds_u32* bt = e + bt_off; // [KB][kw]
-    const uint32_t KB = (ws.ev_words - bt_off) / kw;
+    const uint32_t KB_lds = (ws.ev_words - bt_off) / kw;
+    const bool big = nkeys > 16u * KB_lds && (uint64_t)nkeys * kw <= (uint64_t)A.nslots2 * A.np * kPlaneWords && !(dbg & 1024u);
+    const uint32_t KB = big ? nkeys : KB_lds;
     for (uint32_t k0 = 0; k0 < nkeys; k0 += KB) {
       const uint32_t kn = min(KB, nkeys - k0);
-      for (uint32_t i = lane; i < kn * kw; i += 64) bt[i] = 0;
-      WAVE_SYNC();
-      for (uint32_t h = 0; h < A.np; ++h) {
-        if (!((lv >> h) & 1u)) continue;
-        for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
-          const uint32_t i = t0 + lane;
-          const uint32_t v = i < nev ? ev_at(t0, i) : 0xFFFFFFFFu;
-          const uint32_t o = (v >> 12) - k0;
-          if ((v & 31u) == h && o < kn) {
-            const uint32_t pos = (v >> 5) & 127u, bit = 1u << (pos & 31u);
-            const uint32_t old = __hip_atomic_fetch_or(&bt[o * kw + (pos >> 5)], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (!(old & bit))
-              __hip_atomic_fetch_add(&bt[o * kw + kPlaneWords + (h >> 2)], 1u << (8u * (h & 3u)), __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-        }
-        WAVE_SYNC();
+      const uint64_t tl0 = (dbg & 512u) ? __builtin_readcyclecounter() : 0;
+      if (!(dbg & 128u)) {
+        if (big)
+          plane_pass(A.g_planes, A.np, k0, kn, nev, ev_at);
+        else
+          plane_pass(bt, A.np, k0, kn, nev, ev_at);
       }
+      if ((dbg & 512u) && lane == 0) atomicAdd(&out.counters[16], (uint32_t)((__builtin_readcyclecounter() - tl0) >> 6));
       // ---- 4. one lane per key of the batch
       for (uint32_t j0 = 0; j0 < kn; j0 += 64) {
         const uint32_t j = j0 + lane;
@@ -1006,9 +1141,10 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
 #pragma unroll
         for (int q = 0; q < kHistWords; ++q) c[q] = 0;
         if (j < kn) {
-#pragma unroll
-          for (int q = 0; q < kHistWords; ++q)
-            if ((uint32_t)q < hw) c[q] = bt[j * kw + kPlaneWords + q];
+          if (big)
+            plane_counts(A.g_planes, A.np, j, c);
+          else
+            plane_counts(bt, A.np, j, c);
           rs = kt_lds ? keytab[k0 + j] : gload(&gkt[k0 + j]);
           uint32_t hmin = 0xFFFFFFFFu; // hdist_min = lowest hd with a non-zero counter
 #pragma unroll
@@ -1036,6 +1172,18 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
       }
       WAVE_SYNC();
     }
+    if ((dbg & 512u) && lane == 0) { // statistics for tuning
+      atomicAdd(&out.counters[9], nev);
+      atomicAdd(&out.counters[10], nkeys);
+      atomicAdd(&out.counters[11], KB ? (nkeys + KB - 1) / KB : 0u);
+      atomicAdd(&out.counters[12], big ? 1u : 0u);
+      atomicAdd(&out.counters[13], (uint32_t)__popc(lv) * ((nev + 63) / 64));
+      atomicMax(&out.counters[14], nkeys);
+      atomicMax(&out.counters[15], nev);
+    }
+    if (big && nkeys) { // the plane path expects its global tables all-zero
+      for (uint32_t i = lane; i < nkeys * kw; i += 64) gstore(&A.g_planes[i], 0u);
+    }
     if (fits) {
       fits = nrec <= tab_cap + ws.gtab_cap;
       if (nrec > tab_cap) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1046,7 +1194,7 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
         out.rd_off[read] = rbase == 0xFFFFFFFFu ? 0 : rbase;
         out.rd_cnt[read] = rbase == 0xFFFFFFFFu ? 0 : nrec;
       }
-      if (nrec && rbase != 0xFFFFFFFFu) {
+      if (nrec && rbase != 0xFFFFFFFFu && !(dbg & 256u)) {
         for (uint32_t t0 = 0; t0 < nrec; t0 += 64) {
           const uint32_t t = t0 + lane;
           if (t >= nrec) break;
@@ -1105,6 +1253,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   const uint32_t onmers = out.rd_onmers[read];
   const uint32_t filt0 = out.rd_filt[2 * read], filt1 = out.rd_filt[2 * read + 1];
   bool l2_any = false; // wave-uniform: some key of this read lives in level 2
+  const uint64_t tr0 = (P.dbg & 512u) ? __builtin_readcyclecounter() : 0;
   ws.evmode = nkm <= (uint64_t)kSegPos && !(P.dbg & 8u); // single segment: event mode
   // A read is processed once; only if its events do not fit (buffer or tables) is it processed a
   // second time with the plane tables.
@@ -1122,21 +1271,25 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   ws.l2 = false;
   ws.nev = 0;
   ws.ev_full = false;
-  uint32_t cur_seg = 0;
   for (uint32_t t0 = 0; t0 < ((P.dbg & 2u) ? 0u : nit); t0 += 64) {
     const uint32_t i = t0 + lane;
     const bool valid = i < nit;
-    uint2 it = make_uint2(0, 0);
+    uint2 it = make_uint2(0, kItemMarker);
     if (valid) it = items[i];
-    const uint32_t seg = it.y >> 17;
-    for (;;) { // the items of a tile are in segment order; more than one segment only for long reads
+    const bool marker = (it.y & kItemMarker) != 0;
+    uint32_t se = 0;
+    if (valid && !marker) // the colour of the table entry the scan kernel matched
+      se = get_lib<SL>(ix, tag_lib(it.y)).se[(uint64_t)it.x | ((uint64_t)((it.y >> 17) & 0xFFu) << 32)];
+    uint64_t todo = __ballot(valid);
+    for (;;) { // markers (reads of more than one segment only) split the tile
+      const uint64_t mk = __ballot(valid && marker) & todo;
+      const uint64_t upto = mk ? (1ull << (__ffsll((long long)mk) - 1)) - 1ull : ~0ull;
       if (ws.top > (uint32_t)(kStackUse - 128)) expand_all<SL>(ix, A, ws);
-      expand_step<SL>(ix, A, ws, valid && seg == cur_seg, it.x, it.y & 0x1FFFFu);
-      const uint64_t later = __ballot(valid && seg > cur_seg);
-      if (later == 0) break;
+      expand_step<SL>(ix, A, ws, valid && !marker && ((todo & upto) >> lane & 1ull), se, it.y & 0x1FFFFu);
+      if (mk == 0) break;
       expand_all<SL>(ix, A, ws);
-      segment_fold(A, ws, l2_any);
-      cur_seg = __shfl(seg, __ffsll((long long)later) - 1);
+      segment_fold(A, ws, l2_any); // the segment before the marker is complete
+      todo &= ~(upto | (upto + 1ull));
     }
   }
   expand_all<SL>(ix, A, ws);
@@ -1146,7 +1299,14 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   if (!ws.evmode) break;
   if (P.dbg & 16u) ws.nev = 0, ws.ev_full = false;
   if ((P.dbg & 32u) && ws.ev_full) ws.nev = 0, ws.ev_full = false;
-  if (!ws.ev_full && finalize_events(ix, out, A, ws, hist_tbl, hist_words, read, filt0, filt1, P.dbg)) return;
+  const uint64_t tf0 = (P.dbg & 512u) ? __builtin_readcyclecounter() : 0;
+  const bool fin_ok = !ws.ev_full && finalize_events(ix, out, A, ws, hist_tbl, hist_words, read, filt0, filt1, P.dbg);
+  if ((P.dbg & 512u) && lane == 0) {
+    const uint64_t tf1 = __builtin_readcyclecounter();
+    atomicAdd(&out.counters[17], (uint32_t)((tf1 - tf0) >> 6));
+    atomicAdd(&out.counters[18], (uint32_t)((tf1 - tr0) >> 6));
+  }
+  if (fin_ok) return;
   ws.evmode = false; // does not fit: redo the read with the plane tables
   } // redo loop
   // records that pass `hdist_min <= 2*hdist_filt+1` (src/query.cpp:101-106,119), ordered by key so
@@ -1300,14 +1460,11 @@ __global__ __launch_bounds__(kWave, 4) void kr_acc_kernel_t(DevIndex ix, DevPara
   ws.gev_cap = out.ev_spill;
   ws.gtab_cap = out.tab_spill;
   ws.gkt_cap = out.kt_spill;
-  for (;;) {
-    uint32_t r0 = 0;
-    if (lane_id() == 0) r0 = atomicAdd(&out.counters[8], kReadChunk);
-    r0 = __shfl(r0, 0);
-    if (r0 >= in.nreads) break;
-    const uint32_t r1 = min(r0 + kReadChunk, in.nreads);
+  ReadCursor rc;
+  rc.init(out.cursors + kCursors * kCursorStride, in.nreads, blockIdx.x);
+  uint32_t r0, r1;
+  while (rc.next(r0, r1))
     for (uint32_t r = r0; r < r1; ++r) process_read<SL>(ix, P, in, out, r, A, ws, (lds_u32*)s_base, kStackCap * 2 + kLdsSlots);
-  }
   if (ws.n_l2 && lane_id() == 0) atomicAdd(&out.counters[2], ws.n_l2);
   if (ws.n_rec && lane_id() == 0) atomicAdd(&out.counters[4], ws.n_rec);
 }
@@ -2222,7 +2379,8 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   if ((rc = halloc(s.get(), &ptr, (n)))) { kr_stream_destroy(s.release()); return rc; }
   SA(s->d_bases, max_bases + 256);
   SA(s->d_offsets, (uint64_t)max_reads + 1);
-  SA(o.counters, 16);
+  SA(o.counters, 32);
+  SA(o.cursors, 2 * kCursors * kCursorStride);
   SA(o.rd_off, max_reads);
   SA(o.rd_cnt, max_reads);
   SA(o.rd_onmers, max_reads);
@@ -2257,7 +2415,7 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   HIP_TRY(hipMemset(o.g_counts, 0, (uint64_t)s->nwaves * nslots2 * np * 4));
   HA(s->h_bases, max_bases + 256);
   HA(s->h_offsets, (uint64_t)max_reads + 1);
-  HA(s->h_counters, 8);
+  HA(s->h_counters, 32);
   HA(s->h_rd_off, max_reads);
   HA(s->h_rd_cnt, max_reads);
   HA(s->h_rd_onmers, max_reads);
@@ -2309,7 +2467,8 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
     s->in.offsets = s->d_offsets;
   }
   s->in.nreads = nreads;
-  HIP_TRY(hipMemsetAsync(s->out.counters, 0, 64, st));
+  HIP_TRY(hipMemsetAsync(s->out.counters, 0, 128, st));
+  HIP_TRY(hipMemsetAsync(s->out.cursors, 0, 2 * kCursors * kCursorStride * 4, st));
   HIP_TRY(hipMemsetAsync(s->out.rec_key, 0, (uint64_t)s->rec_cap * 4, st));
   HIP_TRY(hipMemsetAsync(s->out.rec_sel, 0, (uint64_t)s->rec_cap, st));
   HIP_TRY(hipEventRecord(s->ev[1], st));
@@ -2377,9 +2536,16 @@ int kr_batch_wait(kr_stream* s)
   if (!s || !s->submitted) return kr::fail(KR_ERR_STATE, "kr_batch_wait: nothing submitted");
   if (s->waited) return KR_OK;
   HIP_TRY(hipSetDevice(s->ix->device));
-  HIP_TRY(hipMemcpyAsync(s->h_counters, s->out.counters, 32, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->h_counters, s->out.counters, 128, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->waited = true;
+  if (s->dp.dbg & 512u)
+    fprintf(stderr, "[kr stats] reads %u events %u keys %u batches %u big %u level-tiles %u max keys %u max events %u records %u\n", s->nreads,
+            s->h_counters[9], s->h_counters[10], s->h_counters[11], s->h_counters[12], s->h_counters[13], s->h_counters[14],
+            s->h_counters[15], s->h_counters[4]);
+  if (s->dp.dbg & 512u)
+    fprintf(stderr, "[kr stats] wave cycles/64 per launch: level passes %u (zero %u, event passes %u, key passes %u), finalize %u, whole read %u\n",
+            s->h_counters[16], s->h_counters[19], s->h_counters[20], s->h_counters[21], s->h_counters[17], s->h_counters[18]);
   s->nrecs = std::min(s->h_counters[0], s->rec_cap);
   s->nhits = std::min<uint64_t>(s->h_counters[3], s->hit_cap);
   if (s->h_counters[4] > s->rec_user_cap)
