@@ -94,7 +94,9 @@ struct LlhConst {
 struct DevParams {
   uint32_t th, np;       // np = th + 1 planes
   uint32_t multi, no_filter, dmax_set;
-  uint32_t dbg; // KR_DEBUG_SKIP (timing experiments only): 1 drop hits, 2 drop expansion, 4 skip scan, 8 no event mode, 16 drop events
+  uint32_t dbg; // KR_DEBUG_SKIP (timing experiments / tests only): 1 drop hits, 2 drop expansion, 4 skip scan, 8 no event mode,
+                // 16 drop events, 64 no batches, 128 no plane pass, 256 no record output, 512 statistics, 1024 never / 2048
+                // eagerly use the global single batch
   double chisq, dist_max;
 };
 
@@ -1120,7 +1122,7 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
     const uint32_t bt_off = (nev_lds + (kt_lds ? nkeys : 0u) + 3u) & ~3u; // 16-byte aligned
     lds_u32* bt = e + bt_off; // [KB][kw]
     const uint32_t KB_lds = (ws.ev_words - bt_off) / kw;
-    const bool big = nkeys > 16u * KB_lds && (uint64_t)nkeys * kw <= (uint64_t)A.nslots2 * A.np * kPlaneWords && !(dbg & 1024u);
+    const bool big = nkeys > ((dbg & 2048u) ? 1u : 16u) * KB_lds && (uint64_t)nkeys * kw <= (uint64_t)A.nslots2 * A.np * kPlaneWords && !(dbg & 1024u);
     const uint32_t KB = big ? nkeys : KB_lds;
     for (uint32_t k0 = 0; k0 < nkeys; k0 += KB) {
       const uint32_t kn = min(KB, nkeys - k0);

@@ -248,6 +248,37 @@ def test_overflow_path_many_leaves(capi, po, synth, tmp_path):
     assert e.value.code == capi.KR_ERR_CAPACITY
 
 
+@pytest.mark.parametrize("dbg", ["0", "2048", "8"])
+def test_single_segment_many_leaves_spill_paths(capi, po, synth, tmp_path, monkeypatch, dbg):
+    """150-bp reads (one 128-position segment: event mode) against 160 close relatives: thousands of events and
+    hundreds of (leaf, strand) keys per read -> events spill to global scratch, the epilogue runs several plane
+    batches (or, forced by the debug bit, the single batch in global scratch; or, with event mode off, the
+    level-1/level-2 plane tables), the passing-key table spills.  Histograms must be bit-exact in every mode."""
+    n = 160
+    names = [f"s{i}" for i in range(n)]
+    nwk = "(" + ",".join(f"{x}:0.003" for x in names) + ");"
+    g = synth.evolve_genomes(nwk, 5000, seed=17)
+    tsv = synth.write_genomes(g, str(tmp_path / "g"))
+    (tmp_path / "t.nwk").write_text(nwk)
+    idx = str(tmp_path / "ix")
+    capi.build_index(tsv, idx, nwk=str(tmp_path / "t.nwk"), k=29, w=31, h=13, m=2, r=0, frac=True, num_threads=4)
+    hx = capi.HostIndex(idx)
+    dx = hx.upload(0)
+    ox = po.Index(idx)
+    bases, offs, rn = synth.sample_reads(g, 300, seed=9)
+    ref = ox.dist(bases, offs, rn, po.params(collect=7))
+    monkeypatch.setenv("KR_DEBUG_SKIP", dbg)
+    st = dx.stream(max_reads=300, max_bases=len(bases), max_records=300 * 2 * n)
+    st.submit(bases, offs, capi.KR_TAP_ACCS)
+    res = st.collect()
+    acc = ref["accs"][ref["accs"]["passed"] == 1]
+    assert len(acc) > 300 * 100  # the point of the test: many keys per read
+    want = sorted(zip(acc["read"].tolist(), ((acc["se"] << 1) | acc["strand"]).tolist(), [tuple(x[:5]) for x in acc["hist"].tolist()]))
+    got = sorted(zip(res.rec_read.tolist(), res.rec_key.tolist(), [tuple(x) for x in res.rec_hist.tolist()]))
+    assert got == want
+    assert_rows_close(res.rows(), rows_of_oracle(ref))
+
+
 def test_device_brent_vs_oracle(capi, po, toy):
     hx, dx, ox = toy
     rng = np.random.default_rng(31)
