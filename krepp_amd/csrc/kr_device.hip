@@ -68,8 +68,10 @@ struct DevLib {
   const uint32_t* se;   // [nkmers] colour ids
   const uint2* pse;     // [nsubsets] colour DAG: colour = union of .x and .y
   const double* rho;    // [nnodes] subsampling rates, already scaled
+  const uint32_t* slots; // [nrows << slot_log2w] slotted copy of the head of every bucket (dense tables), or null
   uint64_t nkmers;
   uint32_t nrows, nsubsets, nnodes, numer;
+  uint32_t slot_log2w;  // words per slot = 1 << slot_log2w: {len, start, first (words - 2) residual codes}
 };
 
 struct DevIndex {
@@ -467,8 +469,9 @@ struct Cand { // one lane's two candidate probes (forward, reverse) of a positio
   uint32_t lib0, lib1;
 };
 
-// front end + descriptor loads for positions 64*pp + lane
-template <bool SL>
+// front end + descriptor loads for positions 64*pp + lane.  SLOT: the table has a slotted copy, the bucket is
+// found by its row alone (b = 1 << 32 | row, no load here).
+template <bool SL, bool SLOT>
 __device__ __forceinline__ Cand fetch_group(const DevIndex& ix, const SegBits& sb, int pp, uint32_t npos_seg,
                                             uint32_t& nvalid)
 {
@@ -482,11 +485,11 @@ __device__ __forceinline__ Cand fetch_group(const DevIndex& ix, const SegBits& s
   c.q1 = fe.enc32[1];
   if (fe.valid && locate_row<SL>(ix, fe.rix[0], lib, row)) {
     c.lib0 = (uint32_t)lib;
-    c.b0 = get_lib<SL>(ix, (uint32_t)lib).bkt[row];
+    c.b0 = SLOT ? (1ull << 32) | row : get_lib<SL>(ix, (uint32_t)lib).bkt[row];
   }
   if (fe.valid && locate_row<SL>(ix, fe.rix[1], lib, row)) {
     c.lib1 = (uint32_t)lib;
-    c.b1 = get_lib<SL>(ix, (uint32_t)lib).bkt[row];
+    c.b1 = SLOT ? (1ull << 32) | row : get_lib<SL>(ix, (uint32_t)lib).bkt[row];
   }
   return c;
 }
@@ -729,7 +732,107 @@ __device__ __forceinline__ void scan_group(const DevIndex& ix, const DevParams& 
   }
 }
 
+// Scan of one group's probe list through the SLOTTED table (dense tables): row r owns an aligned slot of
+// W = G*CPL*4 words = {bucket length, packed start index, the first W-2 residual codes}.  One pass reads the
+// whole slot of 64/G probes -- no descriptor gather in front (one dependent HBM round trip and one
+// L2->fabric request per probe less: the kernel runs at the chip's random-request rate), always the same
+// two lines per probe.  The two header words take part in the hit test like entries and are rejected, like
+// every entry beyond the bucket's length, when the hit chunks are resolved.  The rest of a bucket longer than
+// W-2 entries is read from the packed array and resolved on the spot.
 template <int LOG_G, int CPL, bool SL, bool TAP>
+__device__ __forceinline__ void scan_group_slots(const DevIndex& ix, const DevParams& P, const BatchOut& out, ScanWave& sw,
+                                                 const ProbeList& pl, lds_u32* queue, uint32_t nact, uint32_t read, uint32_t base0)
+{
+  constexpr uint32_t G = 1u << LOG_G, PPS = 64u >> LOG_G, W = G * CPL * 4u, CAP = W - 2u;
+  static_assert((kListCap / PPS) * CPL <= 64, "one hit bit per (pass, chunk)");
+  const uint32_t lane = lane_id(), sub = lane & (G - 1u);
+  uint64_t hitbits = 0;
+  uint32_t step = 0;
+  for (uint32_t p0 = 0; p0 < nact; p0 += PPS, step += CPL) {
+    const uint32_t pi = p0 + (lane >> LOG_G);
+    const bool on = pi < nact;
+    const uint32_t row = on ? (uint32_t)pl.bkt[pi] : 0u;
+    const uint32_t q = on ? pl.q[pi] : 0u;
+    const DevLib L = get_lib<SL>(ix, SL ? 0u : tag_lib(pl.tag[on ? pi : 0u]));
+    const uint32_t* slot = L.slots + (uint64_t)row * W;
+    uint4 v[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      v[j] = make_uint4(0, 0, 0, 0);
+      if (on) v[j] = *reinterpret_cast<const uint4*>(slot + 4u * (sub + (uint32_t)j * G));
+    }
+    uint32_t r = 0;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const uint32_t m = min(min(hd_lr32(v[j].x, q), hd_lr32(v[j].y, q)), min(hd_lr32(v[j].z, q), hd_lr32(v[j].w, q)));
+      r |= (m <= P.th && on) ? (1u << j) : 0u;
+    }
+    hitbits |= (uint64_t)r << step;
+    // ---- buckets longer than the slot: the rest from the packed array, resolved on the spot
+    if (__ballot(on && sub == 0 && v[0].x > CAP) != 0) {
+      const uint32_t blen = __shfl(v[0].x, lane & ~(G - 1u)), bstart = __shfl(v[0].y, lane & ~(G - 1u));
+      const bool lg = on && blen > CAP;
+      const uint64_t st = (uint64_t)bstart + CAP;
+      const uint64_t e_al = st & ~3ull;
+      const int rel0 = (int)(st & 3u), tot = rel0 + (lg ? (int)(blen - CAP) : 0);
+      const uint32_t nch = lg ? (uint32_t)(tot + 3) >> 2 : 0u;
+      const uint32_t tg = pl.tag[on ? pi : 0u];
+      for (uint32_t c = sub; __ballot(c < nch) != 0; c += G) {
+        uint32_t pend = 0, hds = 0;
+        if (c < nch) {
+          const uint4 w = *reinterpret_cast<const uint4*>(L.enc + e_al + 4u * c);
+          pend = chunk_hits(w, rel0 - 4 * (int)c, tot - 4 * (int)c, q, P.th, hds);
+        }
+        if (P.dbg & 1u) pend = 0;
+        emit_hits<SL, TAP>(ix, out, sw, read, base0, tg, e_al, c, pend, hds);
+      }
+    }
+  }
+  if (P.dbg & 1u) hitbits = 0;
+  // ---- deal the hit chunks out, 64 at a time: re-read header + chunk, apply the bucket bounds, emit
+  const uint32_t cnt = (uint32_t)__popcll(hitbits);
+  uint32_t inc = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d);
+    if (lane >= (uint32_t)d) inc += o;
+  }
+  const uint32_t H = __shfl(inc, 63);
+  uint64_t hb = hitbits;
+  uint32_t slot_i = inc - cnt;
+  for (uint32_t w0 = 0; w0 < H; w0 += 64) {
+    while (__ballot(hb != 0 && slot_i < w0 + 64u) != 0) {
+      if (hb != 0 && slot_i < w0 + 64u) {
+        const uint32_t bit = (uint32_t)__ffsll((long long)hb) - 1u;
+        const uint32_t pass = bit / (uint32_t)CPL, j = bit - pass * (uint32_t)CPL;
+        queue[slot_i - w0] = (pass * PPS + (lane >> LOG_G)) | ((sub + j * G) << 8);
+        hb &= hb - 1;
+        ++slot_i;
+      }
+    }
+    WAVE_SYNC();
+    uint32_t pend = 0, hds = 0, tg = 0, c = 0;
+    uint64_t e_al = 0;
+    if (lane < min(64u, H - w0)) {
+      const uint32_t d = queue[lane], probe = d & 255u;
+      c = d >> 8;
+      const uint32_t row = (uint32_t)pl.bkt[probe];
+      const uint32_t q = pl.q[probe];
+      tg = pl.tag[probe];
+      const uint32_t* slot = get_lib<SL>(ix, tag_lib(tg)).slots + (uint64_t)row * W;
+      const uint2 hdr = *reinterpret_cast<const uint2*>(slot);
+      const uint4 v = *reinterpret_cast<const uint4*>(slot + 4u * c);
+      // word 4c+e of the slot is entry 4c+e-2 of the bucket = packed index start + 4c+e-2
+      const int nin = (int)min(hdr.x, CAP);
+      pend = chunk_hits(v, 2 - 4 * (int)c, nin + 2 - 4 * (int)c, q, P.th, hds);
+      e_al = (uint64_t)hdr.y - 2ull;
+    }
+    WAVE_SYNC();
+    emit_hits<SL, TAP>(ix, out, sw, read, base0, tg, e_al, c, pend, hds);
+  }
+}
+
+template <int LOG_G, int CPL, bool SL, bool TAP, bool SLOT>
 __device__ __forceinline__ void scan_read(const DevIndex& ix, const DevParams& P, const BatchIn& in, const BatchOut& out,
                                           uint32_t read, ScanWave& sw, const ProbeList& pl, lds_u32* queue, lds_u32* stepinfo)
 {
@@ -752,10 +855,10 @@ __device__ __forceinline__ void scan_read(const DevIndex& ix, const DevParams& P
     for (int pp = 0; pp < 2; ++pp) { // unrolled: SegBits stays in scalar registers
       if (pp == 1 && npos_seg <= 64) break;
       uint32_t nv = 0;
-      const Cand cur = fetch_group<SL>(ix, sb, pp, npos_seg, nv);
+      const Cand cur = fetch_group<SL, SLOT>(ix, sb, pp, npos_seg, nv);
       onmers += nv;
-      // ---- compact the non-empty probes of this group into the LDS list
-      const bool a0 = (cur.b0 & 0xFFFFFFu) != 0, a1 = (cur.b1 & 0xFFFFFFu) != 0;
+      // ---- compact the non-empty probes of this group into the LDS list (slotted: every located probe)
+      const bool a0 = SLOT ? cur.b0 != 0 : (cur.b0 & 0xFFFFFFu) != 0, a1 = SLOT ? cur.b1 != 0 : (cur.b1 & 0xFFFFFFu) != 0;
       const uint64_t m0 = __ballot(a0), m1 = __ballot(a1);
       const uint32_t n0 = __popcll(m0), nact = n0 + __popcll(m1);
       if (a0) {
@@ -771,7 +874,12 @@ __device__ __forceinline__ void scan_read(const DevIndex& ix, const DevParams& P
         pl.tag[i] = (64u * pp + lane) | (1u << 7) | (cur.lib1 << 8);
       }
       WAVE_SYNC();
-      if (!(P.dbg & 4u)) scan_group<LOG_G, CPL, SL, TAP>(ix, P, out, sw, pl, queue, stepinfo, nact, read, (uint32_t)base0);
+      if (!(P.dbg & 4u)) {
+        if (SLOT)
+          scan_group_slots<LOG_G, CPL, SL, TAP>(ix, P, out, sw, pl, queue, nact, read, (uint32_t)base0);
+        else
+          scan_group<LOG_G, CPL, SL, TAP>(ix, P, out, sw, pl, queue, stepinfo, nact, read, (uint32_t)base0);
+      }
       WAVE_SYNC();
     }
   }
@@ -794,9 +902,12 @@ __device__ __forceinline__ void scan_read(const DevIndex& ix, const DevParams& P
 #ifndef KR_SCAN_WPE
 #define KR_SCAN_WPE 6 // resident scan waves per SIMD the register allocation is sized for (8 spills, 5 hides less latency)
 #endif
+#ifndef KR_SCAN_WPE_SLOT
+#define KR_SCAN_WPE_SLOT 4 // ... of the slotted variant (one more chunk per lane; 5: 6.0 ms, 6 spills: 7.3 ms, 4: 5.6 ms)
+#endif
 constexpr int kScanWaves = 4; // waves per workgroup of the scan kernel (they share nothing)
-template <int LOG_G, int CPL, bool SL, bool TAP>
-__global__ __launch_bounds__(kScanWaves* kWave, KR_SCAN_WPE) void kr_scan_kernel_t(DevIndex ix, DevParams P, BatchIn in, BatchOut out)
+template <int LOG_G, int CPL, bool SL, bool TAP, bool SLOT>
+__global__ __launch_bounds__(kScanWaves* kWave, (SLOT ? KR_SCAN_WPE_SLOT : KR_SCAN_WPE)) void kr_scan_kernel_t(DevIndex ix, DevParams P, BatchIn in, BatchOut out)
 {
   __shared__ __attribute__((aligned(16))) uint64_t s_bkt[kScanWaves][kListCap];
   __shared__ uint32_t s_q[kScanWaves][kListCap], s_tag[kScanWaves][kListCap], s_queue[kScanWaves][64], s_step[kScanWaves][64];
@@ -813,7 +924,7 @@ __global__ __launch_bounds__(kScanWaves* kWave, KR_SCAN_WPE) void kr_scan_kernel
   rc.init(out.cursors, in.nreads, blockIdx.x * kScanWaves + w);
   uint32_t r0, r1;
   while (rc.next(r0, r1))
-    for (uint32_t r = r0; r < r1; ++r) scan_read<LOG_G, CPL, SL, TAP>(ix, P, in, out, r, sw, pl, queue, stepinfo);
+    for (uint32_t r = r0; r < r1; ++r) scan_read<LOG_G, CPL, SL, TAP, SLOT>(ix, P, in, out, r, sw, pl, queue, stepinfo);
   if (sw.err && lane_id() == 0) atomicOr(&out.counters[1], sw.err);
 }
 
@@ -1833,6 +1944,27 @@ __global__ __launch_bounds__(256) void kr_select_kernel(LlhConst C, DevIndex ix,
   }
 }
 
+// Slotted copy of the head of every bucket: slot r = {len, start, enc[start .. start + W - 2)}, unused words 0xFFFFFFFF.
+// One thread per slot word: reads are contiguous within a bucket, writes fully coalesced.
+__global__ void kr_build_slots(const uint64_t* bkt, const uint32_t* enc, uint32_t nrows, uint32_t log2w, uint32_t* slots)
+{
+  const uint64_t n = (uint64_t)nrows << log2w;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t row = (uint32_t)(i >> log2w), wd = (uint32_t)i & ((1u << log2w) - 1u);
+    const uint64_t b = bkt[row];
+    const uint64_t st = b >> 24;
+    const uint32_t ln = (uint32_t)(b & 0xFFFFFFu);
+    uint32_t x = 0xFFFFFFFFu;
+    if (wd == 0)
+      x = ln;
+    else if (wd == 1)
+      x = (uint32_t)st;
+    else if (wd - 2u < ln)
+      x = enc[st + wd - 2u];
+    slots[i] = x;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Debug kernels
 // ---------------------------------------------------------------------------
@@ -1986,6 +2118,7 @@ LlhConst make_llh_const(uint32_t k, uint32_t h, uint32_t th)
 struct kr_index {
   int device = 0;
   uint32_t log_g = 0;           // lanes per probe in the bucket scan = 2^log_g (from the mean bucket length)
+  uint32_t slot_log2w = 0;      // slotted table copy: words per slot = 1 << slot_log2w (0: none)
   DevIndex dix;
   std::vector<DevLib> hlibs;    // host copy of the device DevLib array
   std::vector<void*> allocs;    // everything to hipFree
@@ -1998,6 +2131,7 @@ namespace {
 
 struct DescHeader {
   uint32_t magic, k, h, m, nlibs, tree_nnodes, nleaves, log_g;
+  uint32_t slot_log2w, pad_; // words per slot of the slotted table copy = 1 << slot_log2w (0: none)
   uint64_t res_mask;
   uint8_t ppos[32], npos[32];
 };
@@ -2047,6 +2181,13 @@ int alloc_from_desc(kr_index* ix, const DescHeader& H, const std::vector<DescLib
     if ((rc = dev_alloc(ix, &p, b))) return rc;
     d.rho = (const double*)p;
     ix->bufs.push_back({p, b});
+    d.slot_log2w = H.slot_log2w;
+    if (H.slot_log2w) {
+      b = ((uint64_t)d.nrows << H.slot_log2w) * 4;
+      if ((rc = dev_alloc(ix, &p, b))) return rc;
+      d.slots = (const uint32_t*)p;
+      ix->bufs.push_back({p, b});
+    }
   }
   void* p;
   int rc;
@@ -2060,6 +2201,7 @@ int alloc_from_desc(kr_index* ix, const DescHeader& H, const std::vector<DescLib
   ix->bufs.push_back({p, b});
   ix->dix.nleaves = H.nleaves;
   ix->log_g = H.log_g;
+  ix->slot_log2w = H.slot_log2w;
   b = (uint64_t)H.m * 4;
   if ((rc = dev_alloc(ix, &p, b))) return rc;
   ix->dix.res_lib = (const int32_t*)p;
@@ -2146,6 +2288,16 @@ int kr_index_upload(const kr_index_view* v, int device, uint32_t flags, kr_index
     H.log_g = mean_len <= 3.0 ? 0u : (mean_len <= 44.0 ? 2u : 3u);
     if (const char* e = getenv("KR_LOG_G")) H.log_g = (uint32_t)atoi(e) > 3 ? 3u : (uint32_t)atoi(e);
     if (H.log_g == 1) H.log_g = 2;
+    // dense tables get a slotted copy of the head of every bucket (see scan_group_slots): the smallest slot
+    // of 32 / 64 / 128 words whose W-2 entries cover the mean bucket length + 3 sigma (Poisson)
+    bool fits32 = true;
+    for (uint32_t i = 0; i < v->nlibs; ++i) fits32 = fits32 && v->libs[i].nkmers < (1ull << 32);
+    const double need = mean_len + 3.0 * std::sqrt(mean_len);
+    if (mean_len >= 12.0 && fits32) H.slot_log2w = need <= 30.0 ? 5u : (need <= 62.0 ? 6u : (need <= 126.0 ? 7u : 0u));
+    if (const char* e = getenv("KR_SLOT_LOG2W")) { // tests / experiments: 0 (packed only), 5, 6, 7
+      const uint32_t w = (uint32_t)atoi(e);
+      H.slot_log2w = (fits32 && w >= 5 && w <= 7) ? w : 0u;
+    }
   }
   std::unique_ptr<kr_index> ix(new kr_index());
   ix->device = device;
@@ -2182,6 +2334,8 @@ int kr_index_upload(const kr_index_view* v, int device, uint32_t flags, kr_index
       hipLaunchKernelGGL(kr_relayout_cmer, dim3(2048), dim3(256), 0, 0, src_cmer, lv.nkmers, (uint32_t*)d.enc, (uint32_t*)d.se,
                          ix->dix.node_info, v->tree_nnodes, lv.nsubsets);
     if (lv.nrows) hipLaunchKernelGGL(kr_relayout_inc, dim3(1024), dim3(256), 0, 0, src_inc, lv.nrows, (uint64_t*)d.bkt, d_bad);
+    if (lv.nrows && H.slot_log2w)
+      hipLaunchKernelGGL(kr_build_slots, dim3(8192), dim3(256), 0, 0, d.bkt, d.enc, lv.nrows, H.slot_log2w, (uint32_t*)d.slots);
     HIP_TRY(hipDeviceSynchronize());
     if (t_cmer) hipFree(t_cmer);
     if (t_inc) hipFree(t_inc);
@@ -2398,7 +2552,7 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   o.rec_cap = s->rec_cap;
   o.hit_cap = s->hit_cap;
   // item list between the two kernels: 256 hits per read on average, plus one partly used chunk per scan wave
-  s->scan_blocks = (uint32_t)prop.multiProcessorCount * (4u * KR_SCAN_WPE / kScanWaves); // resident by construction (launch bounds)
+  s->scan_blocks = (uint32_t)prop.multiProcessorCount * (4u * (ix->slot_log2w ? KR_SCAN_WPE_SLOT : KR_SCAN_WPE) / kScanWaves); // resident by construction (launch bounds)
   o.item_cap = (uint32_t)std::min<uint64_t>((uint64_t)max_reads * 256u + (uint64_t)s->scan_blocks * kScanWaves * 2u * kItemChunk, 1ull << 31);
   SA(o.items, o.item_cap);
   SA(o.rd_it_off, max_reads);
@@ -2487,25 +2641,31 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
   {
     const bool tap = (flags & KR_TAP_HITS) != 0;
     const uint32_t sgrid = std::min<uint32_t>((nreads + kScanWaves - 1) / kScanWaves, s->scan_blocks);
-#define KR_LAUNCH2(LG, CP, SLV)                                                                                              \
+#define KR_LAUNCH2(LG, CP, SLV, SLT)                                                                                          \
   do {                                                                                                                   \
     if (tap)                                                                                                             \
-      hipLaunchKernelGGL((kr_scan_kernel_t<LG, CP, SLV, true>), dim3(sgrid), dim3(kScanWaves* kWave), 0, st, dix, s->dp, s->in, s->out); \
+      hipLaunchKernelGGL((kr_scan_kernel_t<LG, CP, SLV, true, SLT>), dim3(sgrid), dim3(kScanWaves* kWave), 0, st, dix, s->dp, s->in, s->out); \
     else                                                                                                                 \
-      hipLaunchKernelGGL((kr_scan_kernel_t<LG, CP, SLV, false>), dim3(sgrid), dim3(kScanWaves* kWave), 0, st, dix, s->dp, s->in, s->out); \
+      hipLaunchKernelGGL((kr_scan_kernel_t<LG, CP, SLV, false, SLT>), dim3(sgrid), dim3(kScanWaves* kWave), 0, st, dix, s->dp, s->in, s->out); \
   } while (0)
-#define KR_LAUNCH(LG, CP)          \
-  do {                             \
-    if (single)                    \
-      KR_LAUNCH2(LG, CP, true);    \
-    else                           \
-      KR_LAUNCH2(LG, CP, false);   \
+#define KR_LAUNCH(LG, CP, SLT)          \
+  do {                                  \
+    if (single)                         \
+      KR_LAUNCH2(LG, CP, true, SLT);    \
+    else                                \
+      KR_LAUNCH2(LG, CP, false, SLT);   \
   } while (0)
     const bool single = dix.nlibs == 1 && dix.m <= 64;
-    switch (s->ix->log_g) {
-      case 0: KR_LAUNCH(0, 2); break; // sparse tables: a lane per probe
-      case 2: KR_LAUNCH(2, 3); break; // 4 lanes x 3 chunks = 48 entries per pass
-      default: KR_LAUNCH(3, 3); break; // 8 lanes x 3 chunks = 96 entries per pass
+    switch (s->ix->slot_log2w) {
+      case 5: KR_LAUNCH(2, 2, true); break; // slotted table, 128-byte slots: 4 lanes x 2 chunks
+      case 6: KR_LAUNCH(2, 4, true); break; // 256-byte slots: 4 lanes x 4 chunks
+      case 7: KR_LAUNCH(3, 4, true); break; // 512-byte slots: 8 lanes x 4 chunks
+      default:
+        switch (s->ix->log_g) {
+          case 0: KR_LAUNCH(0, 2, false); break; // sparse tables: a lane per probe
+          case 2: KR_LAUNCH(2, 3, false); break; // 4 lanes x 3 chunks = 48 entries per pass
+          default: KR_LAUNCH(3, 3, false); break; // 8 lanes x 3 chunks = 96 entries per pass
+        }
     }
 #undef KR_LAUNCH2
 #undef KR_LAUNCH

@@ -49,6 +49,17 @@ __global__ void gather8(const uint64_t* buf, const uint32_t* idx, uint64_t n, ui
   }
   if (acc == 0x12345678u) sink[0] = acc;
 }
+// 2^25 random 8-byte gathers confined to (mask+1) lines of 128 bytes
+__global__ void gather8m(const uint64_t* buf, const uint32_t* idx, uint64_t n, uint32_t mask, uint32_t* sink)
+{
+  uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  uint32_t acc = 0;
+  for (; g < n; g += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t v = buf[(uint64_t)(idx[g] & mask) * 16];
+    acc ^= (uint32_t)v ^ (uint32_t)(v >> 32);
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
 int main()
 {
   const uint64_t nblocks = 1ull << 25; // 4 GiB of 128-byte blocks
@@ -69,6 +80,9 @@ int main()
   // 2^24 random 256-byte slots of the same buffer: 64 / 128 / 192 bytes of each
   for (uint32_t nj = 1; nj <= 3; ++nj)
     hipLaunchKernelGGL(gather64, dim3(8192), dim3(256), 0, 0, buf, blk, nblocks, nj, sink);
+  // descriptor-table shapes: 8-byte gathers from a 128 MiB and a 256 MiB region (Infinity Cache = 256 MiB)
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(gather8m, dim3(8192), dim3(256), 0, 0, (const uint64_t*)buf, blk, nblocks, (1u << 20) - 1u, sink);
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(gather8m, dim3(8192), dim3(256), 0, 0, (const uint64_t*)buf, blk, nblocks, (1u << 21) - 1u, sink);
   hipDeviceSynchronize();
   printf("gather64 x nj: known bytes per launch: nj * 64 * %llu (+ index)\n", (unsigned long long)(nblocks / 2));
   printf("gather128 known bytes per launch: %llu (+ %llu index bytes)\n", (unsigned long long)(nblocks * 128), (unsigned long long)(nblocks * 4));

@@ -213,9 +213,13 @@ def test_long_reads_and_ragged_batches(capi, po, toy, toy_genomes):
     assert sorted(st.format_dist(hx, names).splitlines()) == sorted(ref["text"].splitlines())
 
 
-def test_overflow_path_many_leaves(capi, po, synth, tmp_path):
+@pytest.mark.parametrize("slot_log2w", ["0", "5", "6"])
+def test_overflow_path_many_leaves(capi, po, synth, tmp_path, monkeypatch, slot_log2w):
     """Reads that reach more (strand, leaf) pairs than the LDS table holds take the
-    global-memory accumulator path; results must not change."""
+    global-memory accumulator path; results must not change.  The table is dense (18 entries per bucket): scanned
+    through the packed arrays ("0"), 128-byte slots (30 entries: some buckets continue in the packed array) and
+    256-byte slots."""
+    monkeypatch.setenv("KR_SLOT_LOG2W", slot_log2w)
     n = 96
     names = [f"s{i}" for i in range(n)]
     # star-ish tree of close relatives: every read matches nearly every genome
