@@ -1617,6 +1617,47 @@ __device__ __forceinline__ double pown_dd(double x, uint32_t n)
   return r.hi + r.lo;
 }
 
+// Natural logarithm of a positive normal double, error < 1 ulp: the argument reduction and the degree-14
+// minimax polynomial of the classic freely distributable libm `log` (x = 2^k (1+f), s = f/(2+f),
+// log(1+f) = f - s (f - R(s^2)), k ln2 added in two pieces), restated without its special cases -- the
+// likelihood only takes logs of numbers in (1e-300, 1].  40 instructions against the 75 of the general
+// device `log`, and the objective takes three per evaluation (55 % of its instructions before).
+__device__ __attribute__((noinline)) double kr_log_general(double x) { return log(x); }
+__device__ __forceinline__ double kr_log(double x)
+{
+#ifdef KR_OCML_LOG
+  return log(x);
+#endif
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return kr_log_general(x); // zero, subnormal, negative, inf, nan
+  int32_t hx = __double2hiint(x);
+  const uint32_t lx = (uint32_t)__double2loint(x);
+  int32_t k = (hx >> 20) - 1023;
+  hx &= 0x000fffff;
+  int32_t i = (hx + 0x95f64) & 0x100000;
+  x = __hiloint2double(hx | (i ^ 0x3ff00000), (int32_t)lx); // normalise x or x/2
+  k += i >> 20;
+  const double f = x - 1.0;
+  const double s = f / (2.0 + f);
+  const double dk = (double)k;
+  const double z = s * s;
+  i = hx - 0x6147a;
+  const double w = z * z;
+  const int32_t j = 0x6b851 - hx;
+  const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  i |= j;
+  const double R = t2 + t1;
+  if (i > 0) {
+    const double hfsq = 0.5 * f * f;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+  }
+  return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
 typedef KR_LDS double lds_f64;
 struct LlhTables { // per-workgroup copies of the binomial tables (uniform LDS reads, no scalar-load stalls)
   lds_f64* bk;  // [k+1]
@@ -1636,8 +1677,8 @@ __device__ __forceinline__ double llh_eval(const LlhConst& C, const LlhTables& T
 {
   double sum = 0.0, lv_m = 0.0;
   double powdc = (C.dbg & 1u) ? pow(1.0 - d, (double)C.k) : pown_dd(1.0 - d, C.k);
-  double logdn = log(1.0 - d);
-  double logdp = log(d) - logdn;
+  double logdn = kr_log(1.0 - d);
+  double logdp = kr_log(d) - logdn;
   logdn *= (double)C.k;
   const double dratio = d / (1.0 - d);
   if (NPT > 0) {
@@ -1654,12 +1695,15 @@ __device__ __forceinline__ double llh_eval(const LlhConst& C, const LlhTables& T
       powdc *= dratio;
     }
   }
+  // (a fully unrolled k = 29 tail with the binomials in SGPRs was tried: 37 SGPR spills, 2 % slower)
+  {
 #pragma unroll 4
-  for (uint32_t x = C.th + 1; x <= C.k; ++x) {
-    lv_m += powdc * T.bk[x];
-    powdc *= dratio;
+    for (uint32_t x = C.th + 1; x <= C.k; ++x) {
+      lv_m += powdc * T.bk[x];
+      powdc *= dratio;
+    }
   }
-  return sum - log(p.rho * lv_m + 1.0 - p.rho) * p.uc;
+  return sum - kr_log(p.rho * lv_m + 1.0 - p.rho) * p.uc;
 }
 
 // boost::math::tools::brent_find_minima(f, 1e-10, 0.5, 16) (src/query.cpp:430);
