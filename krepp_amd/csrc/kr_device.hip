@@ -3,19 +3,16 @@
 //
 // Pipeline per submitted batch (one HIP stream per kr_stream):
 //
-//   kr_probe_kernel      one wave64 per read.  Front end from wave ballots (no LDS, no
-//                        rolling state): every k-mer x strand -> LSH row (rix) and
-//                        residual code (enc32)          [src/query.cpp:40-94,
-//                        src/common.hpp:177-243, src/lshf.cpp:39-69]; bucket lookup
-//                        [src/index.cpp:160-168]; bucket scan with lanes flattened over
-//                        16-byte chunks of the bucket, Hamming filter
-//                        [src/query.cpp:361-368]; colour-DAG expansion from an LDS work
-//                        stack [src/query.cpp:369-387]; per-(strand, leaf) accumulation
-//                        as position bit-planes in an LDS hash table
-//                        [Minfo::update_match, src/query.hpp:153-176]; hdist_filt test
-//                        [src/query.cpp:101-106,119] and record emission.
-//   kr_probe_overflow_kernel  same code, accumulator table in global memory, for reads
-//                        whose leaf set does not fit the LDS table.
+//   kr_scan_kernel       one wave64 per read, 4-6 waves per SIMD.  Front end from wave ballots (no LDS,
+//                        no rolling state): every k-mer x strand -> LSH row (rix) and residual code
+//                        (enc32) [src/query.cpp:40-94, src/common.hpp:177-243, src/lshf.cpp:39-69];
+//                        bucket lookup [src/index.cpp:160-168]; bucket scan with lane groups over
+//                        16-byte chunks of the bucket (slotted or packed table), Hamming filter
+//                        [src/query.cpp:361-368]; output: the read's hit items in HBM.
+//   kr_acc_kernel        one wave64 per read: colour gather, colour-DAG expansion from an LDS work
+//                        stack [src/query.cpp:369-387]; per-(strand, leaf) accumulation as events /
+//                        position bit-planes [Minfo::update_match, src/query.hpp:153-176]; hdist_filt
+//                        test [src/query.cpp:101-106,119] and record emission.
 //   kr_llh_kernel        one lane per (read, strand, leaf) record, lanes refilled as their
 //                        minimisations converge: Brent minimisation of HDistHistLLH in fp64 [src/hdhistllh.hpp:51-96,
 //                        src/query.cpp:426-433, boost::math::tools::brent_find_minima].
