@@ -1515,9 +1515,12 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   __syncthreads();
 }
 
-template <bool SL>
+// NP = th + 1 planes when known at compile time (5: --hdist-th default; the plane loops unroll and the address
+// arithmetic folds), 0 = any threshold.
+template <bool SL, int NP>
 __global__ __launch_bounds__(kWave, 4) void kr_acc_kernel_t(DevIndex ix, DevParams P, BatchIn in, BatchOut out)
 {
+  if (NP) P.np = NP, P.th = NP - 1;
   // One carve of dynamic LDS (base is 16-byte aligned: no static __shared__ in front):
   //   stack | level-1 table (keys, planes, counts) | level-2 bitmap | ordinal prefix
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
@@ -2713,9 +2716,15 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
     HIP_TRY(hipEventRecord(s->ev[2], st));
     const uint32_t lds = probe_lds_bytes(s->dp.np, s->out.bm_words);
     if (single)
-      hipLaunchKernelGGL(kr_acc_kernel_t<true>, dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);
+      if (s->dp.np == 5 && !getenv("KR_DEBUG_NP0"))
+        hipLaunchKernelGGL((kr_acc_kernel_t<true, 5>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);
+      else
+        hipLaunchKernelGGL((kr_acc_kernel_t<true, 0>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);
     else
-      hipLaunchKernelGGL(kr_acc_kernel_t<false>, dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);
+      if (s->dp.np == 5)
+        hipLaunchKernelGGL((kr_acc_kernel_t<false, 5>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);
+      else
+        hipLaunchKernelGGL((kr_acc_kernel_t<false, 0>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);
   }
   HIP_TRY(hipEventRecord(s->ev[3], st));
   if (s->llh.th == 4)
