@@ -349,6 +349,41 @@ def test_index_export_import_roundtrip(capi, toy, toy_reads):
     assert a.rows() == b.rows() and len(a.rows()) > 100
 
 
+def test_export_import_of_a_slotted_index(capi, po, synth, tmp_path, monkeypatch):
+    """A dense table carries a slotted copy of its bucket heads: the replica must receive it too."""
+    import torch
+    n = 40
+    names = [f"s{i}" for i in range(n)]
+    nwk = "(" + ",".join(f"{x}:0.01" for x in names) + ");"
+    g = synth.evolve_genomes(nwk, 8000, seed=21)
+    tsv = synth.write_genomes(g, str(tmp_path / "g"))
+    (tmp_path / "t.nwk").write_text(nwk)
+    idx = str(tmp_path / "ix")
+    capi.build_index(tsv, idx, nwk=str(tmp_path / "t.nwk"), k=21, w=27, h=7, m=4, r=1, frac=True, num_threads=4)
+    monkeypatch.setenv("KR_SLOT_LOG2W", "6")
+    hx = capi.HostIndex(idx)
+    dx = hx.upload(0)
+    desc, bufs = dx.export()
+    dx2, bufs2 = capi.DeviceIndex.import_empty(desc, 0)
+    assert [b for _, b in bufs] == [b for _, b in bufs2]
+    assert dx2.device_bytes == dx.device_bytes
+
+    class DevPtr:
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+    for (p1, nb), (p2, _) in zip(bufs, bufs2):
+        if nb:
+            torch.as_tensor(DevPtr(p2, nb), device="cuda:0").copy_(torch.as_tensor(DevPtr(p1, nb), device="cuda:0"))
+    torch.cuda.synchronize()
+    bases, offs, rn = synth.sample_reads(g, 300, seed=4)
+    ref = po.Index(idx).dist(bases, offs, rn, po.params(collect=1))
+    _, a = gpu_dist(capi, dx, bases, offs)
+    _, b = gpu_dist(capi, dx2, bases, offs)
+    assert a.rows() == b.rows() and len(a.rows()) > 100
+    assert_rows_close(b.rows(), rows_of_oracle(ref))
+
+
 def test_cli_dist_end_to_end(capi, po, toy_index_dir, toy_reads, tmp_path):
     """BASELINE.json configs[0] plumbing: the `krepp dist` binary on an index directory and a FASTQ
     file; stdout must be the reference's header plus the oracle's rows (input order, 5 decimals)."""
