@@ -1040,34 +1040,8 @@ __device__ __forceinline__ uint32_t alloc_records(const BatchOut& out, WaveState
 // Returns false if the read does not fit (more keys than keytab holds, more passing keys than the
 // table and its global spill hold): the caller falls back to the plane tables.
 // ---------------------------------------------------------------------------
-// Lanes of a wave that OR bits into the SAME LDS (or L2) word serialise, 10-15 cycles per lane, and
-// events of one key at neighbouring positions -- the common case -- arrive in consecutive lanes.  This
-// combines runs of consecutive lanes with equal `addr` in registers (segmented inclusive OR-scan on DPP:
-// four row shifts, two row broadcasts) so that only the LAST lane of a run issues the atomic.
-// addr of inactive lanes must be unique (e.g. ~lane).  Returns the bits this lane should OR, `tail` says whether it should.
-__device__ __forceinline__ uint32_t seg_or_combine(uint32_t addr, uint32_t bits, bool& tail)
-{
-  const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)~addr, (int)addr, 0x138, 0xF, 0xF, false); // wave_shr:1
-  uint32_t f = prev != addr ? 1u : 0u, v = bits;                                                              // f: a run starts here
-  const uint32_t nf = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)f, 0x130, 0xF, 0xF, false);              // wave_shl:1
-  tail = nf != 0;
-#define KR_SEG_STEP(CTRL, RMASK)                                                                   \
-  {                                                                                                \
-    const uint32_t tv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, RMASK, 0xF, true);  \
-    const uint32_t tf = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, CTRL, RMASK, 0xF, true);  \
-    v = f ? v : (v | tv);                                                                          \
-    f |= tf;                                                                                       \
-  }
-  KR_SEG_STEP(0x111, 0xF) // row_shr:1
-  KR_SEG_STEP(0x112, 0xF) // row_shr:2
-  KR_SEG_STEP(0x114, 0xF) // row_shr:4
-  KR_SEG_STEP(0x118, 0xF) // row_shr:8
-  KR_SEG_STEP(0x142, 0xA) // row_bcast:15 -> rows 1, 3
-  KR_SEG_STEP(0x143, 0xC) // row_bcast:31 -> rows 2, 3
-#undef KR_SEG_STEP
-  return v;
-}
-
+// (Combining lanes that OR into the same LDS word in registers first -- a segmented OR-scan on DPP -- was
+//  measured: the serialisation it removes costs less than its ~45 instructions, +1..5 % run time.)
 // Batch arrays of the event epilogue live in LDS, or -- for the rare read with more keys than the LDS
 // holds -- in the wave's global scratch (L2): same code, memory operations by pointer type.
 __device__ __forceinline__ void mem_or(lds_u32* p, uint32_t v) { lds_or(p, v); }
@@ -1161,10 +1135,7 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
     for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
       const uint32_t i = t0 + lane;
       const uint32_t rs = i < nev ? ev_at(t0, i) >> 12 : 0u;
-      const uint32_t word = i < nev ? rs >> 5 : ~lane;
-      bool tail;
-      const uint32_t bits = seg_or_combine(word, i < nev ? 1u << (rs & 31u) : 0u, tail);
-      if (i < nev && tail) lds_or(&A.bitmap[word], bits);
+      if (i < nev) lds_or(&A.bitmap[rs >> 5], 1u << (rs & 31u));
     }
     WAVE_SYNC();
     uint32_t nkeys = 0;
