@@ -1643,38 +1643,59 @@ __device__ __forceinline__ void llh_tables_init(const LlhConst& C, lds_f64* bk, 
 
 // HDistHistLLH::operator() (src/hdhistllh.hpp:71-89), same operation order.  NPT = th+1 when known
 // at compile time (histogram in registers), 0 = any th.
+// The objective splits into a part that depends on d alone -- (1-d)^k, two logs, the (k+1)-term sum lv_m:
+// 85 % of the work -- and a cheap combination with the record's histogram.  Same operations, same order,
+// as the single loop of the reference (the two accumulators never meet before the last line).
+struct LlhShared {
+  double logdn, logdp, lv_m; // k log(1-d), log(d) - log(1-d), sum of the likelihood weights
+};
 template <int NPT>
-__device__ __forceinline__ double llh_eval(const LlhConst& C, const LlhTables& T, const LlhProblem& p, double d)
+__device__ __forceinline__ LlhShared llh_dpart(const LlhConst& C, const LlhTables& T, double d)
 {
-  double sum = 0.0, lv_m = 0.0;
+  LlhShared g;
+  double lv_m = 0.0;
   double powdc = (C.dbg & 1u) ? pow(1.0 - d, (double)C.k) : pown_dd(1.0 - d, C.k);
-  double logdn = kr_log(1.0 - d);
-  double logdp = kr_log(d) - logdn;
-  logdn *= (double)C.k;
+  g.logdn = kr_log(1.0 - d);
+  g.logdp = kr_log(d) - g.logdn;
+  g.logdn *= (double)C.k;
   const double dratio = d / (1.0 - d);
   if (NPT > 0) {
 #pragma unroll
     for (int x = 0; x < NPT; ++x) {
-      sum -= (logdn + (double)x * logdp) * p.mc[x];
       lv_m += T.hnk[x] * powdc;
       powdc *= dratio;
     }
   } else {
     for (uint32_t x = 0; x <= C.th; ++x) {
-      sum -= (logdn + (double)x * logdp) * p.mc[x];
       lv_m += T.hnk[x] * powdc;
       powdc *= dratio;
     }
   }
   // (a fully unrolled k = 29 tail with the binomials in SGPRs was tried: 37 SGPR spills, 2 % slower)
-  {
 #pragma unroll 4
-    for (uint32_t x = C.th + 1; x <= C.k; ++x) {
-      lv_m += powdc * T.bk[x];
-      powdc *= dratio;
-    }
+  for (uint32_t x = C.th + 1; x <= C.k; ++x) {
+    lv_m += powdc * T.bk[x];
+    powdc *= dratio;
   }
-  return sum - kr_log(p.rho * lv_m + 1.0 - p.rho) * p.uc;
+  g.lv_m = lv_m;
+  return g;
+}
+template <int NPT>
+__device__ __forceinline__ double llh_combine(const LlhConst& C, const LlhShared& g, const LlhProblem& p)
+{
+  double sum = 0.0;
+  if (NPT > 0) {
+#pragma unroll
+    for (int x = 0; x < NPT; ++x) sum -= (g.logdn + (double)x * g.logdp) * p.mc[x];
+  } else {
+    for (uint32_t x = 0; x <= C.th; ++x) sum -= (g.logdn + (double)x * g.logdp) * p.mc[x];
+  }
+  return sum - kr_log(p.rho * g.lv_m + 1.0 - p.rho) * p.uc;
+}
+template <int NPT>
+__device__ __forceinline__ double llh_eval(const LlhConst& C, const LlhTables& T, const LlhProblem& p, double d)
+{
+  return llh_combine<NPT>(C, llh_dpart<NPT>(C, T, d), p);
 }
 
 // boost::math::tools::brent_find_minima(f, 1e-10, 0.5, 16) (src/query.cpp:430);
@@ -1789,10 +1810,46 @@ __device__ __forceinline__ void load_problem(const LlhConst& C, const uint32_t* 
   p.rho = rho;
 }
 
+// Every minimisation starts with the same two abscissas: the upper bracket end 0.5 and the golden-section point
+// below it, whatever the record.  kr_llh_pre_kernel evaluates the d-part of the objective at those two points
+// ONCE per workgroup and combines it with every record's histogram (one log per evaluation instead of a full
+// evaluation): 2 of the ~11.6 evaluations of a record leave the divergent main loop.  f(0.5) and f(second
+// point) travel in rec_d / rec_v, which the main kernel overwrites with the result.
+__device__ __forceinline__ double brent_second_point()
+{
+  BrentState s;
+  brent_start(s, 0.5, 0.0);
+  double u = 0.0;
+  brent_next(s, u); // golden section from the upper end: no objective value enters
+  return u;
+}
+template <int NPT>
+__global__ __launch_bounds__(256) void kr_llh_pre_kernel(LlhConst C, DevIndex ix, BatchOut out)
+{
+  __shared__ double s_bk[32], s_hnk[kMaxPlanes], s_g[2][3];
+  LlhTables T{(lds_f64*)s_bk, (lds_f64*)s_hnk};
+  llh_tables_init(C, T.bk, T.hnk);
+  if (threadIdx.x < 2) {
+    const LlhShared g = llh_dpart<NPT>(C, T, threadIdx.x == 0 ? 0.5 : brent_second_point());
+    s_g[threadIdx.x][0] = g.logdn, s_g[threadIdx.x][1] = g.logdp, s_g[threadIdx.x][2] = g.lv_m;
+  }
+  __syncthreads();
+  const LlhShared g0{s_g[0][0], s_g[0][1], s_g[0][2]}, g1{s_g[1][0], s_g[1][1], s_g[1][2]};
+  const uint32_t nrec = min(out.counters[0], out.rec_cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += gridDim.x * blockDim.x) {
+    const uint32_t key = out.rec_key[i];
+    if (key == 0) continue; // hole at the end of a wave's record chunk
+    LlhProblem p;
+    load_problem<NPT>(C, out.rec_hist + i, out.rec_cap, out.rd_onmers[out.rec_read[i]], ix.libs[0].rho[key >> 1], p);
+    out.rec_d[i] = llh_combine<NPT>(C, g0, p);
+    out.rec_v[i] = llh_combine<NPT>(C, g1, p);
+  }
+}
+
 // One record per lane, refilled: a lane whose minimisation has converged stores its result and, once
 // kLlhRefill lanes are idle, the idle lanes take the next records of the wave's current chunk (chunks of
-// kLlhChunk records are handed out through counters[5]).  Every step evaluates the objective once for
-// all busy lanes.
+// kLlhChunk records are handed out through counters[5]) together with their first two objective values.
+// Every step evaluates the objective once for all busy lanes.
 #ifndef KR_LLH_REFILL
 #define KR_LLH_REFILL 8
 #endif
@@ -1810,16 +1867,20 @@ __device__ __forceinline__ void llh_records(const LlhConst& C, const LlhTables& 
   const uint32_t kLlhChunk = min(kLlhChunkMax, max(64u, (nrec / (gridDim.x * (blockDim.x / kWave) * 4u)) & ~63u));
   uint32_t next = 0, end = 0; // wave-uniform cursor into the current chunk
   bool more = true;           // wave-uniform: chunks may remain
-  bool busy = false, fresh = false;
+  bool busy = false;
   uint32_t rec = 0;
   LlhProblem p;
   BrentState s;
   for (;;) {
     double u = 0.5;
-    if (busy && !brent_next(s, u)) {
-      out.rec_d[rec] = s.x;
-      out.rec_v[rec] = s.fx;
-      busy = false;
+    bool has_u = false;
+    if (busy) {
+      has_u = brent_next(s, u);
+      if (!has_u) {
+        out.rec_d[rec] = s.x;
+        out.rec_v[rec] = s.fx;
+        busy = false;
+      }
     }
     // ---- refill
     const uint64_t idle = __ballot(!busy);
@@ -1838,8 +1899,18 @@ __device__ __forceinline__ void llh_records(const LlhConst& C, const LlhTables& 
         if (key != 0) { // 0 = hole at the end of a probe wave's record chunk
           rec = mine;
           load_problem<NPT>(C, out.rec_hist + rec, out.rec_cap, out.rd_onmers[out.rec_read[rec]], ix.libs[0].rho[key >> 1], p);
-          busy = fresh = true;
-          u = 0.5;
+          // the first two steps of the minimisation, with the objective values of kr_llh_pre_kernel
+          const double f0 = out.rec_d[rec], f1 = out.rec_v[rec];
+          brent_start(s, 0.5, f0);
+          double u1 = 0.0;
+          brent_next(s, u1);
+          brent_update(s, u1, f1);
+          has_u = brent_next(s, u);
+          busy = has_u;
+          if (!has_u) { // converged at once (not with these brackets, but cheap to honour)
+            out.rec_d[rec] = s.x;
+            out.rec_v[rec] = s.fx;
+          }
         }
       }
       next = min(end, next + (uint32_t)__popcll(idle));
@@ -1849,14 +1920,7 @@ __device__ __forceinline__ void llh_records(const LlhConst& C, const LlhTables& 
       continue;
     }
     // ---- one objective evaluation for every busy lane
-    if (busy) {
-      const double fu = llh_eval<NPT>(C, T, p, u);
-      if (fresh)
-        brent_start(s, u, fu);
-      else
-        brent_update(s, u, fu);
-      fresh = false;
-    }
+    if (has_u) brent_update(s, u, llh_eval<NPT>(C, T, p, u));
   }
 }
 
@@ -2698,10 +2762,13 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
         hipLaunchKernelGGL((kr_acc_kernel_t<false, 0>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);
   }
   HIP_TRY(hipEventRecord(s->ev[3], st));
-  if (s->llh.th == 4)
+  if (s->llh.th == 4) {
+    hipLaunchKernelGGL(kr_llh_pre_kernel<5>, dim3(4096), dim3(256), 0, st, s->llh, dix, s->out);
     hipLaunchKernelGGL(kr_llh_kernel<5>, dim3(2048), dim3(256), 0, st, s->llh, dix, s->out);
-  else
+  } else {
+    hipLaunchKernelGGL(kr_llh_pre_kernel<0>, dim3(4096), dim3(256), 0, st, s->llh, dix, s->out);
     hipLaunchKernelGGL(kr_llh_kernel<0>, dim3(2048), dim3(256), 0, st, s->llh, dix, s->out);
+  }
   {
     const uint32_t sgrid = std::min<uint32_t>((nreads + 7) / 8, 16384u);
     if (s->llh.th == 4)
