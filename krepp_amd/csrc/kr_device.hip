@@ -1810,27 +1810,37 @@ __device__ __forceinline__ void load_problem(const LlhConst& C, const uint32_t* 
   p.rho = rho;
 }
 
-// Every minimisation starts with the same two abscissas: the upper bracket end 0.5 and the golden-section point
-// below it, whatever the record.  kr_llh_pre_kernel evaluates the d-part of the objective at those two points
-// ONCE per workgroup and combines it with every record's histogram (one log per evaluation instead of a full
-// evaluation): 2 of the ~11.6 evaluations of a record leave the divergent main loop.  f(0.5) and f(second
-// point) travel in rec_d / rec_v, which the main kernel overwrites with the result.
-__device__ __forceinline__ double brent_second_point()
+// Every minimisation starts with the same abscissas: the upper bracket end 0.5, the golden-section point below
+// it, and -- two coincident points make the parabolic step degenerate (p = q = 0 exactly) -- a second
+// golden-section point that depends only on WHICH of the first two values is smaller.  kr_llh_pre_kernel
+// evaluates the d-part of the objective at those four points ONCE per workgroup and combines it with every
+// record's histogram (one log per evaluation instead of a full evaluation): 3 of the ~11.6 evaluations of a
+// record leave the divergent main loop.  The three values travel in rec_d / rec_v / rec_chisq, which the later
+// kernels overwrite with their results.
+__device__ __forceinline__ void brent_shared_points(double& u1, double& u2a, double& u2b)
 {
   BrentState s;
-  brent_start(s, 0.5, 0.0);
   double u = 0.0;
-  brent_next(s, u); // golden section from the upper end: no objective value enters
-  return u;
+  brent_start(s, 0.5, 1.0);
+  brent_next(s, u1); // golden section from the upper end: no objective value enters
+  BrentState sa = s, sb = s;
+  brent_update(sa, u1, 0.0); // f(u1) <= f(0.5)
+  brent_next(sa, u2a);
+  brent_update(sb, u1, 2.0); // f(u1) > f(0.5)
+  brent_next(sb, u2b);
+  (void)u;
 }
 template <int NPT>
 __global__ __launch_bounds__(256) void kr_llh_pre_kernel(LlhConst C, DevIndex ix, BatchOut out)
 {
-  __shared__ double s_bk[32], s_hnk[kMaxPlanes], s_g[2][3];
+  __shared__ double s_bk[32], s_hnk[kMaxPlanes], s_g[4][3];
   LlhTables T{(lds_f64*)s_bk, (lds_f64*)s_hnk};
   llh_tables_init(C, T.bk, T.hnk);
-  if (threadIdx.x < 2) {
-    const LlhShared g = llh_dpart<NPT>(C, T, threadIdx.x == 0 ? 0.5 : brent_second_point());
+  double u1, u2a, u2b;
+  brent_shared_points(u1, u2a, u2b);
+  if (threadIdx.x < 4) {
+    const double d = threadIdx.x == 0 ? 0.5 : (threadIdx.x == 1 ? u1 : (threadIdx.x == 2 ? u2a : u2b));
+    const LlhShared g = llh_dpart<NPT>(C, T, d);
     s_g[threadIdx.x][0] = g.logdn, s_g[threadIdx.x][1] = g.logdp, s_g[threadIdx.x][2] = g.lv_m;
   }
   __syncthreads();
@@ -1841,8 +1851,12 @@ __global__ __launch_bounds__(256) void kr_llh_pre_kernel(LlhConst C, DevIndex ix
     if (key == 0) continue; // hole at the end of a wave's record chunk
     LlhProblem p;
     load_problem<NPT>(C, out.rec_hist + i, out.rec_cap, out.rd_onmers[out.rec_read[i]], ix.libs[0].rho[key >> 1], p);
-    out.rec_d[i] = llh_combine<NPT>(C, g0, p);
-    out.rec_v[i] = llh_combine<NPT>(C, g1, p);
+    const double f0 = llh_combine<NPT>(C, g0, p), f1 = llh_combine<NPT>(C, g1, p);
+    const int w = f1 <= f0 ? 2 : 3; // the branch brent_update takes
+    const LlhShared g2{s_g[w][0], s_g[w][1], s_g[w][2]};
+    out.rec_d[i] = f0;
+    out.rec_v[i] = f1;
+    out.rec_chisq[i] = llh_combine<NPT>(C, g2, p);
   }
 }
 
@@ -1899,12 +1913,14 @@ __device__ __forceinline__ void llh_records(const LlhConst& C, const LlhTables& 
         if (key != 0) { // 0 = hole at the end of a probe wave's record chunk
           rec = mine;
           load_problem<NPT>(C, out.rec_hist + rec, out.rec_cap, out.rd_onmers[out.rec_read[rec]], ix.libs[0].rho[key >> 1], p);
-          // the first two steps of the minimisation, with the objective values of kr_llh_pre_kernel
-          const double f0 = out.rec_d[rec], f1 = out.rec_v[rec];
+          // the first three steps of the minimisation, with the objective values of kr_llh_pre_kernel
+          const double f0 = out.rec_d[rec], f1 = out.rec_v[rec], f2 = out.rec_chisq[rec];
           brent_start(s, 0.5, f0);
-          double u1 = 0.0;
+          double u1 = 0.0, u2 = 0.0;
           brent_next(s, u1);
           brent_update(s, u1, f1);
+          brent_next(s, u2);
+          brent_update(s, u2, f2);
           has_u = brent_next(s, u);
           busy = has_u;
           if (!has_u) { // converged at once (not with these brackets, but cheap to honour)
