@@ -1957,10 +1957,13 @@ __global__ __launch_bounds__(256, KR_LLH_WPE) void kr_llh_kernel(LlhConst C, Dev
 // oracle's, so `<=` ties resolve identically.
 // 32 lanes per read, one record per lane (reads have tens of records; all record arrays are read
 // coalesced).
-template <int NPT>
+// FILT: --filter (the chi-square needs an objective evaluation per record); without it the kernel carries no
+// likelihood code and runs at full occupancy.
+template <int NPT, bool FILT>
 __global__ __launch_bounds__(256) void kr_select_kernel(LlhConst C, DevIndex ix, DevParams P, BatchOut out,
                                                         uint32_t nreads)
 {
+  if (!FILT) P.no_filter = 1;
   __shared__ double s_bk[32], s_hnk[kMaxPlanes];
   LlhTables T{(lds_f64*)s_bk, (lds_f64*)s_hnk};
   llh_tables_init(C, T.bk, T.hnk);
@@ -1994,7 +1997,7 @@ __global__ __launch_bounds__(256) void kr_select_kernel(LlhConst C, DevIndex ix,
     double vcl = 0;
     uint32_t kcl = 0;
     if (cl >= 0) kcl = out.rec_key[cl];
-    if (cl >= 0 && !P.no_filter) {
+    if (FILT && cl >= 0 && !P.no_filter) {
       load_problem<NPT>(C, out.rec_hist + cl, out.rec_cap, out.rd_onmers[r], ix.libs[0].rho[kcl >> 1], pc);
       vcl = out.rec_v[cl];
     }
@@ -2028,7 +2031,7 @@ __global__ __launch_bounds__(256) void kr_select_kernel(LlhConst C, DevIndex ix,
           sel = (int)i == cl;
         } else if (P.no_filter) {
           sel = dm;
-        } else {
+        } else if (FILT) {
           chi = 2 * (llh_eval<NPT>(C, T, pc, d) - vcl); // Minfo::likelihood_ratio (src/query.cpp:420-424)
           sel = (chi < P.chisq) && dm;
         }
@@ -2787,10 +2790,18 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
   }
   {
     const uint32_t sgrid = std::min<uint32_t>((nreads + 7) / 8, 16384u);
-    if (s->llh.th == 4)
-      hipLaunchKernelGGL(kr_select_kernel<5>, dim3(sgrid), dim3(256), 0, st, s->llh, dix, s->dp, s->out, nreads);
-    else
-      hipLaunchKernelGGL(kr_select_kernel<0>, dim3(sgrid), dim3(256), 0, st, s->llh, dix, s->dp, s->out, nreads);
+    const bool filt = !s->dp.no_filter && s->dp.multi;
+    if (s->llh.th == 4) {
+      if (filt)
+        hipLaunchKernelGGL((kr_select_kernel<5, true>), dim3(sgrid), dim3(256), 0, st, s->llh, dix, s->dp, s->out, nreads);
+      else
+        hipLaunchKernelGGL((kr_select_kernel<5, false>), dim3(sgrid), dim3(256), 0, st, s->llh, dix, s->dp, s->out, nreads);
+    } else {
+      if (filt)
+        hipLaunchKernelGGL((kr_select_kernel<0, true>), dim3(sgrid), dim3(256), 0, st, s->llh, dix, s->dp, s->out, nreads);
+      else
+        hipLaunchKernelGGL((kr_select_kernel<0, false>), dim3(sgrid), dim3(256), 0, st, s->llh, dix, s->dp, s->out, nreads);
+    }
   }
   HIP_TRY(hipEventRecord(s->ev[4], st));
   HIP_TRY(hipGetLastError());
