@@ -95,7 +95,7 @@ struct DevParams {
   uint32_t multi, no_filter, dmax_set;
   uint32_t dbg; // KR_DEBUG_SKIP (timing experiments / tests only): 1 drop hits, 2 drop expansion, 4 skip scan, 8 no event mode,
                 // 16 drop events, 64 no batches, 128 no plane pass, 256 no record output, 512 statistics, 1024 never / 2048
-                // eagerly use the global single batch
+                // eagerly use the global single batch, 4096 planes for single-event keys too
   double chisq, dist_max;
 };
 
@@ -1160,7 +1160,16 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
     lds_u32* keytab = e + nev_lds;
     uint32_t* gkt = gtab + (uint64_t)ws.gtab_cap * ew;
     const uint32_t tab_cap = lo_words / ew;
-    // ---- 2. ordinals into the events, keys into keytab
+    // ---- 2. ordinals into the events, keys into keytab, events per key into kinfo
+    //         (most keys of a read have ONE event -- relatives reached by a single k-mer -- and need no planes)
+    lds_u32* kinfo = keytab + nkeys;
+    // only where the plain planes would need more than one batch
+    const bool sparse_try = kt_lds && nev_lds + 2u * nkeys + 4u <= ws.ev_words && !(dbg & 4096u) &&
+                            nkeys > (ws.ev_words - ((nev_lds + nkeys + 3u) & ~3u)) / kw;
+    if (sparse_try) {
+      for (uint32_t o = lane; o < nkeys; o += 64) kinfo[o] = 0;
+      WAVE_SYNC();
+    }
     uint32_t lv = 0;
     if (fits)
       for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
@@ -1177,6 +1186,7 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
             keytab[o] = rs;
           else
             gstore(&gkt[o], rs);
+          if (sparse_try) __hip_atomic_fetch_add(&kinfo[o], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           lv |= 1u << (v & 31u);
         }
       }
@@ -1198,16 +1208,47 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
     // ---- 3. batches of KB ordinals; a read with more than 16 LDS batches of keys runs as ONE batch in the
     //         wave's global scratch (A.g_planes, all-zero between reads like the plane path needs it):
     //         L2 atomics are ~10x slower than LDS ones, the batches re-read the events
-    const uint32_t bt_off = (nev_lds + (kt_lds ? nkeys : 0u) + 3u) & ~3u; // 16-byte aligned
+    // kinfo[o] becomes: keys with several events -> their plane slot (consecutive); keys with one event ->
+    // 0x80000000 | hd of that event (filled in by the plane pass)
+    constexpr uint32_t kSingle = 0x80000000u;
+    uint32_t nmulti = 0;
+    if (sparse_try) {
+      for (uint32_t j0 = 0; j0 < nkeys; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const bool multi = j < nkeys && kinfo[j] > 1u;
+        const uint64_t mm = __ballot(multi);
+        if (j < nkeys) kinfo[j] = multi ? nmulti + (uint32_t)__popcll(mm & lt) : (kSingle | 0x40u);
+        nmulti += (uint32_t)__popcll(mm);
+      }
+      WAVE_SYNC();
+    }
+    const bool sparse = sparse_try && nkeys != 0 && ((nev_lds + 2u * nkeys + 3u) & ~3u) + nmulti * kw <= ws.ev_words;
+    const uint32_t bt_off = (nev_lds + (kt_lds ? nkeys : 0u) + (sparse ? nkeys : 0u) + 3u) & ~3u; // 16-byte aligned
     lds_u32* bt = e + bt_off; // [KB][kw]
-    const uint32_t KB_lds = (ws.ev_words - bt_off) / kw;
-    const bool big = nkeys > ((dbg & 2048u) ? 1u : 16u) * KB_lds && (uint64_t)nkeys * kw <= (uint64_t)A.nslots2 * A.np * kPlaneWords && !(dbg & 1024u);
+    const uint32_t KB_lds = sparse ? nkeys : (ws.ev_words - bt_off) / kw;
+    const bool big = !sparse && nkeys > ((dbg & 2048u) ? 1u : 16u) * KB_lds && (uint64_t)nkeys * kw <= (uint64_t)A.nslots2 * A.np * kPlaneWords && !(dbg & 1024u);
     const uint32_t KB = big ? nkeys : KB_lds;
     for (uint32_t k0 = 0; k0 < nkeys; k0 += KB) {
       const uint32_t kn = min(KB, nkeys - k0);
       const uint64_t tl0 = (dbg & 512u) ? __builtin_readcyclecounter() : 0;
       if (!(dbg & 128u)) {
-        if (big)
+        if (sparse) { // one pass, planes for the keys with several events only
+          for (uint32_t i = lane; i < nmulti * kw; i += 64) bt[i] = 0;
+          WAVE_SYNC();
+          for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
+            const uint32_t i = t0 + lane;
+            if (i < nev) {
+              const uint32_t v = ev_at(t0, i), o = v >> 12, ki = kinfo[o];
+              if (ki & kSingle) {
+                kinfo[o] = kSingle | (v & 31u);
+              } else {
+                const uint32_t pos = (v >> 5) & 127u;
+                lds_or(bt + (ki * A.np + (v & 31u)) * kPlaneWords + (pos & 3u), 1u << (pos >> 2));
+              }
+            }
+          }
+          WAVE_SYNC();
+        } else if (big)
           plane_pass(A.g_planes, A.np, k0, kn, nev, ev_at);
         else
           plane_pass(bt, A.np, k0, kn, nev, ev_at);
@@ -1222,7 +1263,17 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
 #pragma unroll
         for (int q = 0; q < kHistWords; ++q) c[q] = 0;
         if (j < kn) {
-          if (big)
+          if (sparse) {
+            const uint32_t ki = kinfo[j];
+            if (ki & kSingle) {
+              const uint32_t hd1 = ki & 31u;
+#pragma unroll
+              for (int q = 0; q < kHistWords; ++q)
+                if ((hd1 >> 2) == (uint32_t)q && !(ki & 0x40u)) c[q] = 1u << (8u * (hd1 & 3u));
+            } else {
+              plane_counts(bt, A.np, ki, c);
+            }
+          } else if (big)
             plane_counts(A.g_planes, A.np, j, c);
           else
             plane_counts(bt, A.np, j, c);
