@@ -102,7 +102,7 @@ struct DevParams {
 // Everything the kernels write for one batch.
 struct BatchOut {
   uint32_t* counters;    // [0] record slots handed out  [1] error flags  [2] reads that used level 2  [3] nhits(tap)  [4] records
-                         // [5] LLH chunk cursor  [6] item slots handed out  [7] scan read cursor  [8] accumulate read cursor
+                         // [5] LLH chunk cursor  [6] item slots handed out  [22] distinct likelihood problems
   uint32_t* cursors;     // read cursors of the scan and the accumulate kernel, [2][kCursors * kCursorStride]
   uint32_t* rd_off;
   uint32_t* rd_cnt;
@@ -116,6 +116,13 @@ struct BatchOut {
   double* rec_v;
   double* rec_chisq;
   uint8_t* rec_sel;
+  // likelihood de-duplication (kr_dedup_kernel): records with the same (leaf, histogram, #k-mers) are one problem
+  uint32_t* rec_rep;     // [rec_cap] position of the record's representative in rep_list (0xFFFFFFFF: hole)
+  uint32_t* rep_list;    // [rec_cap] record index of every distinct problem
+  double2* rep_dv;       // [rec_cap] (d_llh, v_llh) per distinct problem
+  ulonglong2* dd_table;  // [dd_slots] open-addressing table: x = histogram word (0 = empty), y = leaf | (list position + 1) << 32
+  uint32_t dd_slots;     // power of two
+  uint32_t dd_shift;     // slots used per batch = records >> dd_shift (rounded up to a power of two)
   uint32_t rec_cap;
   kr_hit* hits;
   uint32_t hit_cap;
@@ -1861,6 +1868,138 @@ __device__ __forceinline__ void load_problem(const LlhConst& C, const uint32_t* 
   p.rho = rho;
 }
 
+// ---------------------------------------------------------------------------
+// Likelihood de-duplication.  The ML distance of a record is a pure function of (leaf -> rho, histogram,
+// number of k-mers of the read), and a batch repeats the same few problems over and over -- a reference
+// reached by one k-mer at Hamming distance 1 from a 150-bp read is THE most common record.  kr_dedup_kernel
+// finds the distinct problems of the batch with an open-addressing table in HBM (slot = 64-bit histogram
+// word claimed by CAS + 64-bit {leaf, list position}), the likelihood kernels run on the distinct ones, and
+// kr_llh_copy_kernel hands the result to the duplicates.  Nothing is kept between batches.  Records the
+// 64-bit word cannot describe (th != 4, a count above 255, more than 65535 k-mers) are their own problem.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dd_mask(const BatchOut& out)
+{ // table slots used for this batch: a power of two >= (number of record slots) >> dd_shift, at most dd_slots
+  const uint32_t n = min(out.counters[0], out.rec_cap);
+  uint32_t m = 1024;
+  while (m < out.dd_slots && m < (n >> out.dd_shift)) m <<= 1;
+  return m - 1u;
+}
+__global__ __launch_bounds__(256) void kr_dedup_clear_kernel(BatchOut out)
+{
+  const uint32_t n = dd_mask(out) + 1u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out.dd_table[i] = make_ulonglong2(0, 0);
+}
+template <int NPT>
+__global__ __launch_bounds__(256) void kr_dedup_kernel(BatchOut out)
+{
+  const uint32_t nrec = min(out.counters[0], out.rec_cap);
+  const uint32_t mask = dd_mask(out);
+  unsigned long long* tab = reinterpret_cast<unsigned long long*>(out.dd_table);
+  // Once the table is half full a wave stops inserting (look-ups only; new problems stand alone).  The wave learns
+  // it from the list positions its own insertions get: a shared flag polled by every wave was measured at 3x the
+  // kernel's run time -- one word read by the whole chip serialises on its L2 channel.
+  bool crowded = false;
+  for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < nrec; i0 += gridDim.x * blockDim.x) { // wave-uniform trip count
+    const uint32_t i = i0 + threadIdx.x;
+    const uint32_t key = i < nrec ? out.rec_key[i] : 0u;
+    bool todo = key != 0; // 0 = hole at the end of a wave's record chunk
+    bool own = false;     // becomes its own problem without the table
+    uint64_t w0 = 0;
+    uint32_t pos = 0xFFFFFFFFu;
+    const uint32_t se = key >> 1;
+    if (todo) {
+      const uint32_t onmers = out.rd_onmers[out.rec_read[i]];
+      bool fit = NPT == 5 && onmers < 65536u;
+      if (NPT == 5) {
+#pragma unroll
+        for (int x = 0; x < 5; ++x) {
+          const uint32_t hv = out.rec_hist[(uint64_t)x * out.rec_cap + i];
+          fit = fit && hv < 256u;
+          w0 |= (uint64_t)(hv & 255u) << (8 * x);
+        }
+      }
+      w0 |= ((uint64_t)onmers << 40) | (1ull << 63);
+      own = !fit;
+    }
+    uint32_t slot = (uint32_t)((w0 * 0x9E3779B97F4A7C15ull) >> 32) ^ (se * 0x85EBCA6Bu);
+    // Retry loop without an inner spin: a lane that finds its histogram word in a slot whose second word is not
+    // published yet simply comes round again (the publishing lane may be in this very wave).
+    const uint64_t lt = (1ull << lane_id()) - 1ull;
+    for (int it = 0; it < 48 && __ballot(todo && !own) != 0; ++it) {
+      bool won = false;
+      unsigned long long old = 1ull;
+      if (todo && !own) {
+        slot &= mask;
+        // most records find their problem already there: look before the (much slower) atomic
+        old = __hip_atomic_load(&tab[2ull * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0ull) {
+          if (crowded) {
+            own = true; // not in the table and no room for it
+            old = 1ull;
+          } else {
+            old = atomicCAS(&tab[2ull * slot], 0ull, (unsigned long long)w0);
+          }
+        }
+        won = old == 0ull; // claimed: this record represents the problem
+      }
+      // list positions for the winners of this round: ONE atomic per wave (a single word serves ~90 M atomics/s)
+      const uint64_t wm = __ballot(won);
+      if (wm != 0) {
+        uint32_t base = 0;
+        if (lane_id() == (uint32_t)(__ffsll((long long)wm) - 1)) base = atomicAdd(&out.counters[22], (uint32_t)__popcll(wm));
+        base = __shfl(base, __ffsll((long long)wm) - 1);
+        crowded = crowded || base > (mask >> 1);
+        if (won) {
+          pos = base + (uint32_t)__popcll(wm & lt);
+          out.rep_list[pos] = i;
+          __hip_atomic_store(&tab[2ull * slot + 1], (unsigned long long)se | ((unsigned long long)(pos + 1u) << 32), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT); // nothing else is published through it in this kernel
+          todo = false;
+        }
+      }
+      if (todo && !own && !won) {
+        if (old == (unsigned long long)w0) {
+          const unsigned long long w1 = __hip_atomic_load(&tab[2ull * slot + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((uint32_t)(w1 >> 32) != 0u) {
+            if ((uint32_t)w1 == se) { // the same problem
+              pos = (uint32_t)(w1 >> 32) - 1u;
+              todo = false;
+            } else {
+              ++slot; // same histogram, another leaf
+            }
+          } // else: not published yet, same slot again
+        } else {
+          ++slot;
+        }
+      }
+    }
+    { // not describable, or the table is crowded: its own problem
+      const uint64_t om = __ballot(todo);
+      if (om != 0) {
+        uint32_t base = 0;
+        if (lane_id() == (uint32_t)(__ffsll((long long)om) - 1)) base = atomicAdd(&out.counters[22], (uint32_t)__popcll(om));
+        base = __shfl(base, __ffsll((long long)om) - 1);
+        if (todo) {
+          pos = base + (uint32_t)__popcll(om & lt);
+          out.rep_list[pos] = i;
+        }
+      }
+    }
+    if (i < nrec) out.rec_rep[i] = pos;
+  }
+}
+__global__ __launch_bounds__(256) void kr_llh_copy_kernel(BatchOut out)
+{
+  const uint32_t nrec = min(out.counters[0], out.rec_cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += gridDim.x * blockDim.x) {
+    const uint32_t pos = out.rec_rep[i];
+    if (pos == 0xFFFFFFFFu) continue;
+    const double2 dv = out.rep_dv[pos]; // every record takes its value from the table of distinct problems
+    out.rec_d[i] = dv.x;
+    out.rec_v[i] = dv.y;
+  }
+}
+
 // Every minimisation starts with the same abscissas: the upper bracket end 0.5, the golden-section point below
 // it, and -- two coincident points make the parabolic step degenerate (p = q = 0 exactly) -- a second
 // golden-section point that depends only on WHICH of the first two values is smaller.  kr_llh_pre_kernel
@@ -1896,10 +2035,10 @@ __global__ __launch_bounds__(256) void kr_llh_pre_kernel(LlhConst C, DevIndex ix
   }
   __syncthreads();
   const LlhShared g0{s_g[0][0], s_g[0][1], s_g[0][2]}, g1{s_g[1][0], s_g[1][1], s_g[1][2]};
-  const uint32_t nrec = min(out.counters[0], out.rec_cap);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += gridDim.x * blockDim.x) {
+  const uint32_t nrep = out.counters[22];
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nrep; j += gridDim.x * blockDim.x) {
+    const uint32_t i = out.rep_list[j];
     const uint32_t key = out.rec_key[i];
-    if (key == 0) continue; // hole at the end of a wave's record chunk
     LlhProblem p;
     load_problem<NPT>(C, out.rec_hist + i, out.rec_cap, out.rd_onmers[out.rec_read[i]], ix.libs[0].rho[key >> 1], p);
     const double f0 = llh_combine<NPT>(C, g0, p), f1 = llh_combine<NPT>(C, g1, p);
@@ -1925,7 +2064,7 @@ constexpr uint32_t kLlhChunkMax = 2048, kLlhRefill = KR_LLH_REFILL;
 template <int NPT>
 __device__ __forceinline__ void llh_records(const LlhConst& C, const LlhTables& T, const DevIndex& ix, const BatchOut& out)
 {
-  const uint32_t nrec = min(out.counters[0], out.rec_cap);
+  const uint32_t nrec = out.counters[22]; // distinct problems (rep_list)
   const uint32_t lane = lane_id();
   const uint64_t lt = (1ull << lane) - 1ull;
   // chunk size: about four chunks per wave, 64 .. kLlhChunkMax records
@@ -1933,7 +2072,7 @@ __device__ __forceinline__ void llh_records(const LlhConst& C, const LlhTables& 
   uint32_t next = 0, end = 0; // wave-uniform cursor into the current chunk
   bool more = true;           // wave-uniform: chunks may remain
   bool busy = false;
-  uint32_t rec = 0;
+  uint32_t rec = 0, pos = 0;
   LlhProblem p;
   BrentState s;
   for (;;) {
@@ -1942,8 +2081,7 @@ __device__ __forceinline__ void llh_records(const LlhConst& C, const LlhTables& 
     if (busy) {
       has_u = brent_next(s, u);
       if (!has_u) {
-        out.rec_d[rec] = s.x;
-        out.rec_v[rec] = s.fx;
+        out.rep_dv[pos] = make_double2(s.x, s.fx);
         busy = false;
       }
     }
@@ -1960,9 +2098,10 @@ __device__ __forceinline__ void llh_records(const LlhConst& C, const LlhTables& 
       }
       const uint32_t mine = next + __popcll(idle & lt);
       if (!busy && mine < end) {
-        const uint32_t key = out.rec_key[mine];
-        if (key != 0) { // 0 = hole at the end of a probe wave's record chunk
-          rec = mine;
+        pos = mine;
+        rec = out.rep_list[mine];
+        const uint32_t key = out.rec_key[rec];
+        {
           load_problem<NPT>(C, out.rec_hist + rec, out.rec_cap, out.rd_onmers[out.rec_read[rec]], ix.libs[0].rho[key >> 1], p);
           // the first three steps of the minimisation, with the objective values of kr_llh_pre_kernel
           const double f0 = out.rec_d[rec], f1 = out.rec_v[rec], f2 = out.rec_chisq[rec];
@@ -1974,10 +2113,7 @@ __device__ __forceinline__ void llh_records(const LlhConst& C, const LlhTables& 
           brent_update(s, u2, f2);
           has_u = brent_next(s, u);
           busy = has_u;
-          if (!has_u) { // converged at once (not with these brackets, but cheap to honour)
-            out.rec_d[rec] = s.x;
-            out.rec_v[rec] = s.fx;
-          }
+          if (!has_u) out.rep_dv[pos] = make_double2(s.x, s.fx); // converged at once (not with these brackets, but cheap to honour)
         }
       }
       next = min(end, next + (uint32_t)__popcll(idle));
@@ -2698,6 +2834,12 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   SA(o.rec_v, s->rec_cap);
   SA(o.rec_chisq, s->rec_cap);
   SA(o.rec_sel, s->rec_cap);
+  SA(o.rec_rep, s->rec_cap);
+  SA(o.rep_list, s->rec_cap);
+  SA(o.rep_dv, s->rec_cap);
+  o.dd_shift = getenv("KR_DD_SHIFT") ? (uint32_t)atoi(getenv("KR_DD_SHIFT")) : 1u; // measured: 1: 5.1 ms, 3: 5.6, 5: 6.9 (llh + select, syn1000)
+  o.dd_slots = std::min<uint32_t>(next_pow2(std::max<uint32_t>(2048u, s->rec_cap >> o.dd_shift)), 1u << 26);
+  SA(o.dd_table, o.dd_slots);
   o.rec_cap = s->rec_cap;
   o.hit_cap = s->hit_cap;
   // item list between the two kernels: 256 hits per read on average, plus one partly used chunk per scan wave
@@ -2832,13 +2974,17 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
         hipLaunchKernelGGL((kr_acc_kernel_t<false, 0>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);
   }
   HIP_TRY(hipEventRecord(s->ev[3], st));
+  hipLaunchKernelGGL(kr_dedup_clear_kernel, dim3(4096), dim3(256), 0, st, s->out);
   if (s->llh.th == 4) {
+    hipLaunchKernelGGL(kr_dedup_kernel<5>, dim3(4096), dim3(256), 0, st, s->out);
     hipLaunchKernelGGL(kr_llh_pre_kernel<5>, dim3(4096), dim3(256), 0, st, s->llh, dix, s->out);
     hipLaunchKernelGGL(kr_llh_kernel<5>, dim3(2048), dim3(256), 0, st, s->llh, dix, s->out);
   } else {
+    hipLaunchKernelGGL(kr_dedup_kernel<0>, dim3(4096), dim3(256), 0, st, s->out);
     hipLaunchKernelGGL(kr_llh_pre_kernel<0>, dim3(4096), dim3(256), 0, st, s->llh, dix, s->out);
     hipLaunchKernelGGL(kr_llh_kernel<0>, dim3(2048), dim3(256), 0, st, s->llh, dix, s->out);
   }
+  hipLaunchKernelGGL(kr_llh_copy_kernel, dim3(4096), dim3(256), 0, st, s->out);
   {
     const uint32_t sgrid = std::min<uint32_t>((nreads + 7) / 8, 16384u);
     const bool filt = !s->dp.no_filter && s->dp.multi;
