@@ -117,6 +117,7 @@ struct BatchOut {
   double* rec_chisq;
   uint8_t* rec_sel;
   // likelihood de-duplication (kr_dedup_kernel): records with the same (leaf, histogram, #k-mers) are one problem
+  uint64_t* rec_w0;      // [rec_cap] the record's likelihood problem packed in one word by kr_acc_kernel (0: not packable)
   uint32_t* rec_rep;     // [rec_cap] position of the record's representative in rep_list (0xFFFFFFFF: hole)
   uint32_t* rep_list;    // [rec_cap] record index of every distinct problem
   double2* rep_dv;       // [rec_cap] (d_llh, v_llh) per distinct problem
@@ -1120,8 +1121,8 @@ __device__ __forceinline__ uint32_t key_ordinal(const Acc& A, uint32_t rs)
 }
 
 __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchOut& out, const Acc& A, WaveState& ws,
-                                                lds_u32* lo, uint32_t lo_words, uint32_t read, uint32_t filt0,
-                                                uint32_t filt1, uint32_t dbg)
+                                                lds_u32* lo, uint32_t lo_words, uint32_t read, uint32_t onmers,
+                                                uint32_t filt0, uint32_t filt1, uint32_t dbg)
 {
   const uint32_t lane = lane_id();
   const uint64_t lt = (1ull << lane) - 1ull;
@@ -1343,10 +1344,14 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
           const uint32_t rs = in_lds ? lo[t * ew + hw] : gload(&g[hw]);
           out.rec_read[ri] = read;
           out.rec_key[ri] = (ix.leaf_se[rs >> 1] << 1) | (rs & 1u);
+          uint64_t w0 = 0; // the likelihood problem in one word (kr_dedup_kernel): five 8-bit counts, #k-mers, bit 63
           for (uint32_t x = 0; x < A.np; ++x) {
             const uint32_t w = in_lds ? lo[t * ew + (x >> 2)] : gload(&g[x >> 2]);
-            out.rec_hist[(uint64_t)x * out.rec_cap + ri] = (w >> (8u * (x & 3u))) & 255u;
+            const uint32_t hv = (w >> (8u * (x & 3u))) & 255u;
+            out.rec_hist[(uint64_t)x * out.rec_cap + ri] = hv;
+            if (x < 5) w0 |= (uint64_t)hv << (8u * x);
           }
+          out.rec_w0[ri] = (A.np == 5u && onmers < 65536u) ? (w0 | ((uint64_t)onmers << 40) | (1ull << 63)) : 0ull;
         }
       }
     }
@@ -1439,7 +1444,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   if (P.dbg & 16u) ws.nev = 0, ws.ev_full = false;
   if ((P.dbg & 32u) && ws.ev_full) ws.nev = 0, ws.ev_full = false;
   const uint64_t tf0 = (P.dbg & 512u) ? __builtin_readcyclecounter() : 0;
-  const bool fin_ok = !ws.ev_full && finalize_events(ix, out, A, ws, hist_tbl, hist_words, read, filt0, filt1, P.dbg);
+  const bool fin_ok = !ws.ev_full && finalize_events(ix, out, A, ws, hist_tbl, hist_words, read, onmers, filt0, filt1, P.dbg);
   if ((P.dbg & 512u) && lane == 0) {
     const uint64_t tf1 = __builtin_readcyclecounter();
     atomicAdd(&out.counters[17], (uint32_t)((tf1 - tf0) >> 6));
@@ -1474,6 +1479,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
       uint32_t ri = rbase + rank;
       out.rec_read[ri] = read;
       out.rec_key[ri] = (ix.leaf_se[(key >> 1) - 1u] << 1) | (key & 1u);
+      out.rec_w0[ri] = 0; // counts of a multi-segment read may exceed 8 bits: never de-duplicated
       for (uint32_t x = 0; x < A.np; ++x) out.rec_hist[(uint64_t)x * out.rec_cap + ri] = A.counts[lane * A.np + x];
     }
     if (key) { // leave the slot empty for the next read
@@ -1533,6 +1539,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
       uint32_t ri = rbase + run + __popcll(okm & lt);
       out.rec_read[ri] = read;
       out.rec_key[ri] = (ix.leaf_se[slot2 >> 1] << 1) | (slot2 & 1u);
+      out.rec_w0[ri] = 0;
       for (uint32_t x = 0; x < A.np; ++x)
         out.rec_hist[(uint64_t)x * out.rec_cap + ri] = gload(&A.g_counts[(uint64_t)slot2 * A.np + x]);
     }
@@ -1875,8 +1882,10 @@ __device__ __forceinline__ void load_problem(const LlhConst& C, const uint32_t* 
 // finds the distinct problems of the batch with an open-addressing table in HBM (slot = 64-bit histogram
 // word claimed by CAS + 64-bit {leaf, list position}), the likelihood kernels run on the distinct ones, and
 // kr_llh_copy_kernel hands the result to the duplicates.  Nothing is kept between batches.  Records the
-// 64-bit word cannot describe (th != 4, a count above 255, more than 65535 k-mers) are their own problem.
+// 64-bit word cannot describe (th != 4, reads of more than one segment, more than 65535 k-mers) are their own
+// problem.  The word is packed by kr_acc_kernel as it writes the record.
 // ---------------------------------------------------------------------------
+constexpr uint32_t kRepChunk = 16;
 __device__ __forceinline__ uint32_t dd_mask(const BatchOut& out)
 { // table slots used for this batch: a power of two >= (number of record slots) >> dd_shift, at most dd_slots
   const uint32_t n = min(out.counters[0], out.rec_cap);
@@ -1889,7 +1898,6 @@ __global__ __launch_bounds__(256) void kr_dedup_clear_kernel(BatchOut out)
   const uint32_t n = dd_mask(out) + 1u;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out.dd_table[i] = make_ulonglong2(0, 0);
 }
-template <int NPT>
 __global__ __launch_bounds__(256) void kr_dedup_kernel(BatchOut out)
 {
   const uint32_t nrec = min(out.counters[0], out.rec_cap);
@@ -1899,6 +1907,23 @@ __global__ __launch_bounds__(256) void kr_dedup_kernel(BatchOut out)
   // it from the list positions its own insertions get: a shared flag polled by every wave was measured at 3x the
   // kernel's run time -- one word read by the whole chip serialises on its L2 channel.
   bool crowded = false;
+  // list positions come from wave-private chunks of kRepChunk (one shared-counter atomic per chunk: distinct
+  // problems are ~5 % of the records, one winner per wave and round, and a single word serves ~90 M atomics/s);
+  // the unused tail of a wave's last chunk is marked as holes
+  uint32_t lp_next = 0, lp_end = 0;
+  auto take_positions = [&](uint32_t n) -> uint32_t { // wave-uniform
+    if (lp_next + n > lp_end) {
+      for (uint32_t q = lp_next + lane_id(); q < lp_end; q += 64) out.rep_list[q] = 0xFFFFFFFFu;
+      const uint32_t size = max(n, kRepChunk);
+      uint32_t base = 0;
+      if (lane_id() == 0) base = atomicAdd(&out.counters[22], size);
+      base = __shfl(base, 0);
+      lp_next = base, lp_end = base + size;
+    }
+    const uint32_t r = lp_next;
+    lp_next += n;
+    return r;
+  };
   for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < nrec; i0 += gridDim.x * blockDim.x) { // wave-uniform trip count
     const uint32_t i = i0 + threadIdx.x;
     const uint32_t key = i < nrec ? out.rec_key[i] : 0u;
@@ -1908,18 +1933,8 @@ __global__ __launch_bounds__(256) void kr_dedup_kernel(BatchOut out)
     uint32_t pos = 0xFFFFFFFFu;
     const uint32_t se = key >> 1;
     if (todo) {
-      const uint32_t onmers = out.rd_onmers[out.rec_read[i]];
-      bool fit = NPT == 5 && onmers < 65536u;
-      if (NPT == 5) {
-#pragma unroll
-        for (int x = 0; x < 5; ++x) {
-          const uint32_t hv = out.rec_hist[(uint64_t)x * out.rec_cap + i];
-          fit = fit && hv < 256u;
-          w0 |= (uint64_t)(hv & 255u) << (8 * x);
-        }
-      }
-      w0 |= ((uint64_t)onmers << 40) | (1ull << 63);
-      own = !fit;
+      w0 = out.rec_w0[i];
+      own = w0 == 0;
     }
     uint32_t slot = (uint32_t)((w0 * 0x9E3779B97F4A7C15ull) >> 32) ^ (se * 0x85EBCA6Bu);
     // Retry loop without an inner spin: a lane that finds its histogram word in a slot whose second word is not
@@ -1945,9 +1960,7 @@ __global__ __launch_bounds__(256) void kr_dedup_kernel(BatchOut out)
       // list positions for the winners of this round: ONE atomic per wave (a single word serves ~90 M atomics/s)
       const uint64_t wm = __ballot(won);
       if (wm != 0) {
-        uint32_t base = 0;
-        if (lane_id() == (uint32_t)(__ffsll((long long)wm) - 1)) base = atomicAdd(&out.counters[22], (uint32_t)__popcll(wm));
-        base = __shfl(base, __ffsll((long long)wm) - 1);
+        const uint32_t base = take_positions((uint32_t)__popcll(wm));
         crowded = crowded || base > (mask >> 1);
         if (won) {
           pos = base + (uint32_t)__popcll(wm & lt);
@@ -1976,9 +1989,7 @@ __global__ __launch_bounds__(256) void kr_dedup_kernel(BatchOut out)
     { // not describable, or the table is crowded: its own problem
       const uint64_t om = __ballot(todo);
       if (om != 0) {
-        uint32_t base = 0;
-        if (lane_id() == (uint32_t)(__ffsll((long long)om) - 1)) base = atomicAdd(&out.counters[22], (uint32_t)__popcll(om));
-        base = __shfl(base, __ffsll((long long)om) - 1);
+        const uint32_t base = take_positions((uint32_t)__popcll(om));
         if (todo) {
           pos = base + (uint32_t)__popcll(om & lt);
           out.rep_list[pos] = i;
@@ -1987,6 +1998,7 @@ __global__ __launch_bounds__(256) void kr_dedup_kernel(BatchOut out)
     }
     if (i < nrec) out.rec_rep[i] = pos;
   }
+  for (uint32_t q = lp_next + lane_id(); q < lp_end; q += 64) out.rep_list[q] = 0xFFFFFFFFu;
 }
 __global__ __launch_bounds__(256) void kr_llh_copy_kernel(BatchOut out)
 {
@@ -2038,6 +2050,7 @@ __global__ __launch_bounds__(256) void kr_llh_pre_kernel(LlhConst C, DevIndex ix
   const uint32_t nrep = out.counters[22];
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nrep; j += gridDim.x * blockDim.x) {
     const uint32_t i = out.rep_list[j];
+    if (i == 0xFFFFFFFFu) continue; // hole at the end of a wave's chunk of list positions
     const uint32_t key = out.rec_key[i];
     LlhProblem p;
     load_problem<NPT>(C, out.rec_hist + i, out.rec_cap, out.rd_onmers[out.rec_read[i]], ix.libs[0].rho[key >> 1], p);
@@ -2100,8 +2113,8 @@ __device__ __forceinline__ void llh_records(const LlhConst& C, const LlhTables& 
       if (!busy && mine < end) {
         pos = mine;
         rec = out.rep_list[mine];
-        const uint32_t key = out.rec_key[rec];
-        {
+        if (rec != 0xFFFFFFFFu) { // else: hole at the end of a wave's chunk of list positions
+          const uint32_t key = out.rec_key[rec];
           load_problem<NPT>(C, out.rec_hist + rec, out.rec_cap, out.rd_onmers[out.rec_read[rec]], ix.libs[0].rho[key >> 1], p);
           // the first three steps of the minimisation, with the objective values of kr_llh_pre_kernel
           const double f0 = out.rec_d[rec], f1 = out.rec_v[rec], f2 = out.rec_chisq[rec];
@@ -2834,6 +2847,7 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   SA(o.rec_v, s->rec_cap);
   SA(o.rec_chisq, s->rec_cap);
   SA(o.rec_sel, s->rec_cap);
+  SA(o.rec_w0, s->rec_cap);
   SA(o.rec_rep, s->rec_cap);
   SA(o.rep_list, s->rec_cap);
   SA(o.rep_dv, s->rec_cap);
@@ -2976,11 +2990,11 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
   HIP_TRY(hipEventRecord(s->ev[3], st));
   hipLaunchKernelGGL(kr_dedup_clear_kernel, dim3(4096), dim3(256), 0, st, s->out);
   if (s->llh.th == 4) {
-    hipLaunchKernelGGL(kr_dedup_kernel<5>, dim3(4096), dim3(256), 0, st, s->out);
+    hipLaunchKernelGGL(kr_dedup_kernel, dim3(4096), dim3(256), 0, st, s->out);
     hipLaunchKernelGGL(kr_llh_pre_kernel<5>, dim3(4096), dim3(256), 0, st, s->llh, dix, s->out);
     hipLaunchKernelGGL(kr_llh_kernel<5>, dim3(2048), dim3(256), 0, st, s->llh, dix, s->out);
   } else {
-    hipLaunchKernelGGL(kr_dedup_kernel<0>, dim3(4096), dim3(256), 0, st, s->out);
+    hipLaunchKernelGGL(kr_dedup_kernel, dim3(4096), dim3(256), 0, st, s->out);
     hipLaunchKernelGGL(kr_llh_pre_kernel<0>, dim3(4096), dim3(256), 0, st, s->llh, dix, s->out);
     hipLaunchKernelGGL(kr_llh_kernel<0>, dim3(2048), dim3(256), 0, st, s->llh, dix, s->out);
   }
