@@ -1142,8 +1142,11 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
     // ---- 1. mark keys, ordinal prefix per 64-bit block
     for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
       const uint32_t i = t0 + lane;
-      const uint32_t rs = i < nev ? ev_at(t0, i) >> 12 : 0u;
-      if (i < nev) lds_or(&A.bitmap[rs >> 5], 1u << (rs & 31u));
+      // only keys that can pass `hdist_min <= 2*hdist_filt+1` at all: an event within the limit marks its key; the
+      // events of unmarked keys are dropped in step 2 (a read with an exact match keeps a third of its keys)
+      const uint32_t v = i < nev ? ev_at(t0, i) : 0xFFFFFFFFu;
+      const uint32_t rs = v >> 12;
+      if (i < nev && (v & 31u) <= ((rs & 1u) ? lim1 : lim0)) lds_or(&A.bitmap[rs >> 5], 1u << (rs & 31u));
     }
     WAVE_SYNC();
     uint32_t nkeys = 0;
@@ -1184,17 +1187,20 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
         const uint32_t i = t0 + lane;
         if (i < nev) {
           const uint32_t v = ev_at(t0, i), rs = v >> 12;
+          const bool live = (A.bitmap[rs >> 5] >> (rs & 31u)) & 1u; // its key was marked
           const uint32_t o = key_ordinal(A, rs);
-          const uint32_t nv = (o << 12) | (v & 0xFFFu);
+          const uint32_t nv = live ? (o << 12) | (v & 0xFFFu) : 0xFFFFFFFFu; // dead events match no batch
           if (t0 < ws.ev_cap)
             e[i] = nv;
           else
             gstore(&ws.gev[i - ws.ev_cap], nv);
-          if (kt_lds)
-            keytab[o] = rs;
-          else
-            gstore(&gkt[o], rs);
-          if (sparse_try) __hip_atomic_fetch_add(&kinfo[o], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (live) {
+            if (kt_lds)
+              keytab[o] = rs;
+            else
+              gstore(&gkt[o], rs);
+            if (sparse_try) __hip_atomic_fetch_add(&kinfo[o], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
           lv |= 1u << (v & 31u);
         }
       }
@@ -1246,8 +1252,10 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
           for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
             const uint32_t i = t0 + lane;
             if (i < nev) {
-              const uint32_t v = ev_at(t0, i), o = v >> 12, ki = kinfo[o];
-              if (ki & kSingle) {
+              const uint32_t v = ev_at(t0, i), o = v >> 12, ki = o < nkeys ? kinfo[o] : 0u;
+              if (o >= nkeys) {
+                // dead event
+              } else if (ki & kSingle) {
                 kinfo[o] = kSingle | (v & 31u);
               } else {
                 const uint32_t pos = (v >> 5) & 127u;
