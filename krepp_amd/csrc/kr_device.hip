@@ -13,9 +13,14 @@
 //                        stack [src/query.cpp:369-387]; per-(strand, leaf) accumulation as events /
 //                        position bit-planes [Minfo::update_match, src/query.hpp:153-176]; hdist_filt
 //                        test [src/query.cpp:101-106,119] and record emission.
-//   kr_llh_kernel        one lane per (read, strand, leaf) record, lanes refilled as their
-//                        minimisations converge: Brent minimisation of HDistHistLLH in fp64 [src/hdhistllh.hpp:51-96,
+//   kr_dedup_kernel      the distinct likelihood problems (leaf, histogram, #k-mers) of the batch, found with
+//                        an open-addressing table in HBM; nothing is kept between batches.
+//   kr_llh_pre_kernel    the first three objective values of every distinct problem (shared abscissas: the
+//                        d-dependent part of the objective is evaluated once per workgroup).
+//   kr_llh_kernel        one lane per distinct problem, lanes refilled as their minimisations converge:
+//                        Brent minimisation of HDistHistLLH in fp64 [src/hdhistllh.hpp:51-96,
 //                        src/query.cpp:426-433, boost::math::tools::brent_find_minima].
+//   kr_llh_copy_kernel   (d, v) of its problem to every record.
 //   kr_select_kernel     32 lanes per read, one record per lane: strand merge, closest reference, --filter /
 //                        --dist-max / --no-multi selection [src/query.cpp:96-139,158-196].
 //
