@@ -1492,8 +1492,15 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
       uint32_t ri = rbase + rank;
       out.rec_read[ri] = read;
       out.rec_key[ri] = (ix.leaf_se[(key >> 1) - 1u] << 1) | (key & 1u);
-      out.rec_w0[ri] = 0; // counts of a multi-segment read may exceed 8 bits: never de-duplicated
-      for (uint32_t x = 0; x < A.np; ++x) out.rec_hist[(uint64_t)x * out.rec_cap + ri] = A.counts[lane * A.np + x];
+      uint64_t w0 = 0; // the likelihood problem in one word (kr_dedup_kernel), if the counts fit 8 bits
+      bool fit = A.np == 5u && onmers < 65536u;
+      for (uint32_t x = 0; x < A.np; ++x) {
+        const uint32_t hv = A.counts[lane * A.np + x];
+        out.rec_hist[(uint64_t)x * out.rec_cap + ri] = hv;
+        fit = fit && hv < 256u;
+        if (x < 5) w0 |= (uint64_t)(hv & 255u) << (8u * x);
+      }
+      out.rec_w0[ri] = fit ? (w0 | ((uint64_t)onmers << 40) | (1ull << 63)) : 0ull;
     }
     if (key) { // leave the slot empty for the next read
       A.keys[lane] = 0;
@@ -1552,9 +1559,15 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
       uint32_t ri = rbase + run + __popcll(okm & lt);
       out.rec_read[ri] = read;
       out.rec_key[ri] = (ix.leaf_se[slot2 >> 1] << 1) | (slot2 & 1u);
-      out.rec_w0[ri] = 0;
-      for (uint32_t x = 0; x < A.np; ++x)
-        out.rec_hist[(uint64_t)x * out.rec_cap + ri] = gload(&A.g_counts[(uint64_t)slot2 * A.np + x]);
+      uint64_t w0 = 0;
+      bool fit = A.np == 5u && onmers < 65536u;
+      for (uint32_t x = 0; x < A.np; ++x) {
+        const uint32_t hv = gload(&A.g_counts[(uint64_t)slot2 * A.np + x]);
+        out.rec_hist[(uint64_t)x * out.rec_cap + ri] = hv;
+        fit = fit && hv < 256u;
+        if (x < 5) w0 |= (uint64_t)(hv & 255u) << (8u * x);
+      }
+      out.rec_w0[ri] = fit ? (w0 | ((uint64_t)onmers << 40) | (1ull << 63)) : 0ull;
     }
     if (t < n2)
       for (uint32_t x = 0; x < A.np; ++x) gstore(&A.g_counts[(uint64_t)slot2 * A.np + x], 0);
@@ -1895,8 +1908,7 @@ __device__ __forceinline__ void load_problem(const LlhConst& C, const uint32_t* 
 // finds the distinct problems of the batch with an open-addressing table in HBM (slot = 64-bit histogram
 // word claimed by CAS + 64-bit {leaf, list position}), the likelihood kernels run on the distinct ones, and
 // kr_llh_copy_kernel hands the result to the duplicates.  Nothing is kept between batches.  Records the
-// 64-bit word cannot describe (th != 4, reads of more than one segment, more than 65535 k-mers) are their own
-// problem.  The word is packed by kr_acc_kernel as it writes the record.
+// 64-bit word cannot describe (th != 4, a count above 255, more than 65535 k-mers) are their own problem.  The word is packed by kr_acc_kernel as it writes the record.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kRepChunk = 16;
 __device__ __forceinline__ uint32_t dd_mask(const BatchOut& out)
