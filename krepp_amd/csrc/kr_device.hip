@@ -100,7 +100,8 @@ struct DevParams {
   uint32_t multi, no_filter, dmax_set;
   uint32_t dbg; // KR_DEBUG_SKIP (timing experiments / tests only): 1 drop hits, 2 drop expansion, 4 skip scan, 8 no event mode,
                 // 16 drop events, 64 no batches, 128 no plane pass, 256 no record output, 512 statistics, 1024 never / 2048
-                // eagerly use the global single batch, 4096 planes for single-event keys too
+                // eagerly use the global single batch, 4096 planes for single-event keys too, 8192 plane tables for reads of
+                // several segments
   double chisq, dist_max;
 };
 
@@ -297,6 +298,7 @@ struct Acc {
   lds_u32* counts;  // [kLdsSlots * np]
   // level 2
   lds_u32* bitmap;   // LDS [bm_words] (bm_words even, 8-byte aligned)
+  lds_u32* rbitmap;  // LDS [bm_words]: keys of the READ so far (event mode over several segments)
   lds_u16* pre;      // LDS [bm_words / 2]: key ordinal prefix per 64-bit bitmap block (event mode)
   uint32_t* g_planes; // global [nslots2 * np * 4]
   uint32_t* g_counts; // global [nslots2 * np]
@@ -971,13 +973,13 @@ __device__ __forceinline__ void fold_l2(const Acc& A, uint32_t slot2)
 }
 
 // list of touched level-2 slots, ascending (= ascending key); returns its length
-__device__ __forceinline__ uint32_t l2_build_list(const Acc& A)
+__device__ __forceinline__ uint32_t l2_build_list(const Acc& A, lds_u32* bitmap)
 {
   const uint32_t lane = lane_id();
   uint32_t n = 0;
   for (uint32_t w0 = 0; w0 < A.bm_words; w0 += 64) {
     uint32_t wi = w0 + lane;
-    uint32_t word = wi < A.bm_words ? A.bitmap[wi] : 0u;
+    uint32_t word = wi < A.bm_words ? bitmap[wi] : 0u;
     uint32_t c = __popc(word), inc = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1125,6 +1127,10 @@ __device__ __forceinline__ uint32_t key_ordinal(const Acc& A, uint32_t rs)
   return (uint32_t)A.pre[blk] + __popcll(bits & ((1ull << (rs & 63u)) - 1ull));
 }
 
+// MERGE: one segment of a longer read -- every key is kept (the hdist_filt test needs the whole read), the
+// segment's counts are added to the wave's global count table (disjoint positions: histograms add) and the key
+// is noted in the read's bitmap; records are written by the caller when the read is complete.
+template <bool MERGE>
 __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchOut& out, const Acc& A, WaveState& ws,
                                                 lds_u32* lo, uint32_t lo_words, uint32_t read, uint32_t onmers,
                                                 uint32_t filt0, uint32_t filt1, uint32_t dbg)
@@ -1151,7 +1157,7 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
       // events of unmarked keys are dropped in step 2 (a read with an exact match keeps a third of its keys)
       const uint32_t v = i < nev ? ev_at(t0, i) : 0xFFFFFFFFu;
       const uint32_t rs = v >> 12;
-      if (i < nev && (v & 31u) <= ((rs & 1u) ? lim1 : lim0)) lds_or(&A.bitmap[rs >> 5], 1u << (rs & 31u));
+      if (i < nev && (MERGE || (v & 31u) <= ((rs & 1u) ? lim1 : lim0))) lds_or(&A.bitmap[rs >> 5], 1u << (rs & 31u));
     }
     WAVE_SYNC();
     uint32_t nkeys = 0;
@@ -1303,7 +1309,17 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
 #pragma unroll
           for (int q = kHistWords - 1; q >= 0; --q)
             if (c[q]) hmin = 4u * q + ((uint32_t)(__ffs((int)c[q]) - 1) >> 3);
-          ok = hmin <= ((rs & 1u) ? lim1 : lim0);
+          ok = !MERGE && hmin <= ((rs & 1u) ? lim1 : lim0);
+          if (MERGE && hmin != 0xFFFFFFFFu) { // this lane owns the key: plain read-modify-write
+            for (uint32_t x = 0; x < A.np; ++x) {
+              const uint32_t cnt = (c[x >> 2] >> (8u * (x & 3u))) & 255u;
+              if (cnt) {
+                uint32_t* cp = &A.g_counts[(uint64_t)rs * A.np + x];
+                gstore(cp, gload(cp) + cnt);
+              }
+            }
+            lds_or(&A.rbitmap[rs >> 5], 1u << (rs & 31u));
+          }
         }
         const uint64_t okm = __ballot(ok);
         if (ok) {
@@ -1341,7 +1357,7 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
       fits = nrec <= tab_cap + ws.gtab_cap;
       if (nrec > tab_cap) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
-    if (fits) {
+    if (fits && !MERGE) {
       const uint32_t rbase = nrec ? alloc_records(out, ws, nrec) : 0u;
       if (lane == 0) {
         out.rd_off[read] = rbase == 0xFFFFFFFFu ? 0 : rbase;
@@ -1368,7 +1384,7 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
         }
       }
     }
-  } else if (lane == 0) {
+  } else if (!MERGE && lane == 0) {
     out.rd_off[read] = 0;
     out.rd_cnt[read] = 0;
   }
@@ -1389,7 +1405,7 @@ __device__ __forceinline__ void segment_fold(const Acc& A, WaveState& ws, bool& 
   if (A.keys[lane_id()]) fold_l1(A, lane_id()); // kLdsSlots == 64: lane t owns slot t
   l2_any = __ballot(ws.l2) != 0;
   if (l2_any) {
-    const uint32_t n2 = l2_build_list(A);
+    const uint32_t n2 = l2_build_list(A, A.bitmap);
     for (uint32_t t = lane_id(); t < n2; t += 64) fold_l2(A, A.g_list[t]);
   }
   __syncthreads();
@@ -1411,7 +1427,11 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   const uint32_t filt0 = out.rd_filt[2 * read], filt1 = out.rd_filt[2 * read + 1];
   bool l2_any = false; // wave-uniform: some key of this read lives in level 2
   const uint64_t tr0 = (P.dbg & 512u) ? __builtin_readcyclecounter() : 0;
-  ws.evmode = nkm <= (uint64_t)kSegPos && !(P.dbg & 8u); // single segment: event mode
+  // Event mode: always for reads of one segment; reads of several segments run it per segment and merge the
+  // segments' counts in the wave's global count table (debug bit 8192 sends them to the plane tables instead).
+  const bool multi = nkm > (uint64_t)kSegPos;
+  ws.evmode = !(P.dbg & 8u) && (!multi || !(P.dbg & 8192u));
+  bool merged = false; // wave-uniform: the read's segments were merged through the count table
   // A read is processed once; only if its events do not fit (buffer or tables) is it processed a
   // second time with the plane tables.
   for (;;) {
@@ -1428,6 +1448,18 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   ws.l2 = false;
   ws.nev = 0;
   ws.ev_full = false;
+  bool seg_ok = true; // every segment so far went through the event epilogue
+  // the segment before a marker (or the last one) is complete
+  auto segment_done = [&]() {
+    if (!ws.evmode) {
+      segment_fold(A, ws, l2_any);
+    } else if (multi) {
+      seg_ok = seg_ok && !ws.ev_full &&
+               finalize_events<true>(ix, out, A, ws, hist_tbl, hist_words, read, onmers, filt0, filt1, P.dbg);
+      ws.nev = 0;
+      ws.ev_full = false;
+    }
+  };
   for (uint32_t t0 = 0; t0 < ((P.dbg & 2u) ? 0u : nit); t0 += 64) {
     const uint32_t i = t0 + lane;
     const bool valid = i < nit;
@@ -1445,19 +1477,33 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
       expand_step<SL>(ix, A, ws, valid && !marker && ((todo & upto) >> lane & 1ull), se, it.y & 0x1FFFFu);
       if (mk == 0) break;
       expand_all<SL>(ix, A, ws);
-      segment_fold(A, ws, l2_any); // the segment before the marker is complete
+      segment_done();
       todo &= ~(upto | (upto + 1ull));
     }
   }
   expand_all<SL>(ix, A, ws);
-  if (!ws.evmode) segment_fold(A, ws, l2_any);
+  if (!ws.evmode || multi) segment_done();
   if (ws.err && lane == 0) atomicOr(&out.counters[1], ws.err);
   ws.err = 0;
   if (!ws.evmode) break;
+  if (multi) {
+    if (seg_ok) { // records from the merged counts, below
+      merged = true;
+      break;
+    }
+    // a segment did not fit: take back what the others added, then the plane tables
+    const uint32_t n2 = l2_build_list(A, A.rbitmap);
+    for (uint32_t t = lane; t < n2; t += 64)
+      for (uint32_t x = 0; x < A.np; ++x) gstore(&A.g_counts[(uint64_t)A.g_list[t] * A.np + x], 0);
+    for (uint32_t w = lane; w < A.bm_words; w += 64) A.rbitmap[w] = 0;
+    __syncthreads();
+    ws.evmode = false;
+    continue;
+  }
   if (P.dbg & 16u) ws.nev = 0, ws.ev_full = false;
   if ((P.dbg & 32u) && ws.ev_full) ws.nev = 0, ws.ev_full = false;
   const uint64_t tf0 = (P.dbg & 512u) ? __builtin_readcyclecounter() : 0;
-  const bool fin_ok = !ws.ev_full && finalize_events(ix, out, A, ws, hist_tbl, hist_words, read, onmers, filt0, filt1, P.dbg);
+  const bool fin_ok = !ws.ev_full && finalize_events<false>(ix, out, A, ws, hist_tbl, hist_words, read, onmers, filt0, filt1, P.dbg);
   if ((P.dbg & 512u) && lane == 0) {
     const uint64_t tf1 = __builtin_readcyclecounter();
     atomicAdd(&out.counters[17], (uint32_t)((tf1 - tf0) >> 6));
@@ -1470,7 +1516,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   // that the two strands of a leaf are adjacent
   const uint32_t lim0 = 2u * filt0 + 1u, lim1 = 2u * filt1 + 1u; // u32 wrap keeps "none" = max
 
-  if (!l2_any) {
+  if (!l2_any && !merged) {
     // ---- level 1 only: lane t owns slot t
     const uint32_t key = A.keys[lane]; // (rank + 1) << 1 | strand: ascending key == ascending colour id
     const bool ok = key && hmin_l1(A, lane) <= ((key & 1u) ? lim1 : lim0);
@@ -1510,8 +1556,10 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
     return;
   }
 
-  // ---- level 2 in use: move the level-1 entries over, then emit from the sorted slot list
-  {
+  // ---- level 2 in use (or segments merged through the count table): move the level-1 entries over, then emit
+  //      from the sorted slot list
+  lds_u32* const bitmap = merged ? A.rbitmap : A.bitmap;
+  if (!merged) {
     const uint32_t key = A.keys[lane];
     if (key) {
       uint32_t slot2 = key - 2u;
@@ -1528,7 +1576,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
     }
     __syncthreads();
   }
-  const uint32_t n2 = l2_build_list(A);
+  const uint32_t n2 = l2_build_list(A, bitmap);
   uint32_t nrec = 0;
   for (uint32_t t0 = 0; t0 < n2; t0 += 64) {
     uint32_t t = t0 + lane;
@@ -1539,7 +1587,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
     }
     nrec += __popcll(__ballot(ok));
   }
-  ws.n_l2++;
+  if (!merged) ws.n_l2++;
   const uint32_t rbase = nrec ? alloc_records(out, ws, nrec) : 0u;
   if (lane == 0) {
     out.rd_off[read] = rbase == 0xFFFFFFFFu ? 0 : rbase;
@@ -1573,7 +1621,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
       for (uint32_t x = 0; x < A.np; ++x) gstore(&A.g_counts[(uint64_t)slot2 * A.np + x], 0);
     run += __popcll(okm);
   }
-  for (uint32_t w = lane; w < A.bm_words; w += 64) A.bitmap[w] = 0;
+  for (uint32_t w = lane; w < A.bm_words; w += 64) bitmap[w] = 0;
   __syncthreads();
 }
 
@@ -1596,7 +1644,8 @@ __global__ __launch_bounds__(kWave, 4) void kr_acc_kernel_t(DevIndex ix, DevPara
   A.planes = A.keys + kLdsSlots;
   A.counts = A.planes + kLdsSlots * P.np * kPlaneWords;
   A.bitmap = A.counts + kLdsSlots * P.np;
-  A.pre = (lds_u16*)(A.bitmap + out.bm_words);
+  A.rbitmap = A.bitmap + out.bm_words;
+  A.pre = (lds_u16*)(A.rbitmap + out.bm_words);
   A.nslots2 = out.nslots2;
   A.bm_words = out.bm_words;
   const uint64_t w = blockIdx.x;
@@ -1611,7 +1660,7 @@ __global__ __launch_bounds__(kWave, 4) void kr_acc_kernel_t(DevIndex ix, DevPara
 #pragma unroll
       for (int q = 0; q < kPlaneWords; ++q) A.planes[(lane * P.np + x) * kPlaneWords + q] = 0;
     }
-    for (uint32_t q = lane; q < A.bm_words; q += 64) A.bitmap[q] = 0;
+    for (uint32_t q = lane; q < A.bm_words; q += 64) A.bitmap[q] = 0, A.rbitmap[q] = 0;
   }
   __syncthreads();
   WaveState ws;
@@ -2412,7 +2461,7 @@ __global__ void kr_relayout_inc(const uint64_t* inc, uint32_t nrows, uint64_t* b
 uint32_t probe_lds_bytes(uint32_t np, uint32_t bm_words)
 {
   uint32_t b = kStackCap * 8;
-  b += kLdsSlots * 4 + kLdsSlots * np * kPlaneWords * 4 + kLdsSlots * np * 4 + bm_words * 4 + bm_words; // + u16 prefix per 2 words
+  b += kLdsSlots * 4 + kLdsSlots * np * kPlaneWords * 4 + kLdsSlots * np * 4 + 2 * bm_words * 4 + bm_words; // two bitmaps + u16 prefix per 2 words
   if (getenv("KR_DEBUG_LDS_PAD")) b += (uint32_t)atoi(getenv("KR_DEBUG_LDS_PAD")); // occupancy experiments
   return (b + 15u) & ~15u;
 }

@@ -213,13 +213,16 @@ def test_long_reads_and_ragged_batches(capi, po, toy, toy_genomes):
     assert sorted(st.format_dist(hx, names).splitlines()) == sorted(ref["text"].splitlines())
 
 
-@pytest.mark.parametrize("slot_log2w", ["0", "5", "6"])
-def test_overflow_path_many_leaves(capi, po, synth, tmp_path, monkeypatch, slot_log2w):
-    """Reads that reach more (strand, leaf) pairs than the LDS table holds take the
-    global-memory accumulator path; results must not change.  The table is dense (18 entries per bucket): scanned
-    through the packed arrays ("0"), 128-byte slots (30 entries: some buckets continue in the packed array) and
-    256-byte slots."""
+@pytest.mark.parametrize("slot_log2w,dbg", [("0", "8192"), ("5", "8192"), ("6", "8192"), ("6", "0")])
+def test_overflow_path_many_leaves(capi, po, synth, tmp_path, monkeypatch, slot_log2w, dbg):
+    """150-bp reads with k = 21 have 130 k-mer positions = two segments.  With debug bit 8192 they take the
+    plane tables, and reads that reach more (strand, leaf) pairs than the LDS table holds go on to the
+    global-memory accumulators; without it every segment runs in event mode and the segments are merged through
+    the global count table.  Results must not change.  The table is dense (18 entries per bucket): scanned through
+    the packed arrays ("0"), 128-byte slots (30 entries: some buckets continue in the packed array) and 256-byte
+    slots."""
     monkeypatch.setenv("KR_SLOT_LOG2W", slot_log2w)
+    monkeypatch.setenv("KR_DEBUG_SKIP", dbg)
     n = 96
     names = [f"s{i}" for i in range(n)]
     # star-ish tree of close relatives: every read matches nearly every genome
@@ -238,7 +241,7 @@ def test_overflow_path_many_leaves(capi, po, synth, tmp_path, monkeypatch, slot_
     st = dx.stream(max_reads=400, max_bases=len(bases), max_records=400 * 2 * n)
     st.submit(bases, offs, capi.KR_TAP_ACCS)
     res = st.collect()
-    assert st.timing().overflow_reads > 50
+    assert (st.timing().overflow_reads > 50) == (dbg == "8192")
     acc = ref["accs"][ref["accs"]["passed"] == 1]
     want = sorted(zip(acc["read"].tolist(), ((acc["se"] << 1) | acc["strand"]).tolist(), [tuple(x[:5]) for x in acc["hist"].tolist()]))
     got = sorted(zip(res.rec_read.tolist(), res.rec_key.tolist(), [tuple(x) for x in res.rec_hist.tolist()]))
