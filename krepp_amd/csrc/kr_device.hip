@@ -2886,7 +2886,10 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
   // resident waves per CU: LDS-limited (160 KiB per CU), VGPR-limited to 4 waves per SIMD
   const uint32_t nslots2 = std::max<uint32_t>(2u, 2u * ix->dix.nleaves), bm_words = ((nslots2 + 63) / 64) * 2;
-  uint32_t per_cu = std::min<uint32_t>(20u, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words));
+  // resident accumulate waves per CU: LDS-limited, at most 16 by registers (4 per SIMD); reads are handed out
+  // dynamically, so a grid that is not fully resident costs nothing
+  uint32_t per_cu = std::min<uint32_t>(16u, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words));
+  if (getenv("KR_DEBUG_ACC_WAVES")) per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(getenv("KR_DEBUG_ACC_WAVES")));
   s->nwaves = (uint32_t)prop.multiProcessorCount * std::max<uint32_t>(1u, per_cu);
   // default record capacity: up to 2 * leaves per read, at most 16 per read on average
   uint64_t per_read = std::min<uint64_t>(16, std::max<uint64_t>(8, (uint64_t)ix->dix.tree_nnodes + 1));
