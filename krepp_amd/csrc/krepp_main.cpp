@@ -17,6 +17,7 @@
 #include <cstring>
 #include <ctime>
 #include <deque>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -176,7 +177,9 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
 
   auto worker = [&](int g) {
     kr_stream* st = nullptr;
-    if (kr_stream_create(dix[g], place ? &pfront : &p, max_reads, max_bases, place ? (uint64_t)max_reads * 128 : 0, &st)) {
+    uint64_t max_records = (uint64_t)max_reads * (place ? 128 : 64);
+    if (const char* e = getenv("KR_DEBUG_CLI_RECORDS")) max_records = strtoull(e, nullptr, 10); // tests: force the split-and-retry path
+    if (kr_stream_create(dix[g], place ? &pfront : &p, max_reads, max_bases, max_records, &st)) {
       std::lock_guard<std::mutex> lk(mu);
       worker_err = kr_last_error();
       cv_done.notify_all();
@@ -194,32 +197,47 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
       cv_work.notify_all(); // the reader may be waiting for queue space
       std::vector<const char*> nm(j->names.size());
       for (size_t i = 0; i < nm.size(); ++i) nm[i] = j->names[i].c_str();
-      kr_result_view rv;
-      char* txt = nullptr;
-      uint64_t len = 0;
-      int rc = kr_batch_submit(st, j->bases.data(), j->offsets.data(), (uint32_t)j->names.size(),
-                               KR_BASES_HOST | (place ? KR_TAP_ACCS : 0u));
-      if (!rc) rc = kr_batch_collect(st, &rv);
-      if (!rc && !place && !summarize) rc = kr_format_dist(hx, &rv, nm.data(), &txt, &len);
-      if (!rc && summarize) { // each read shares one unit among the references it keeps (src/query.cpp:168-170)
-        std::lock_guard<std::mutex> lk(mu);
-        for (uint32_t r = 0; r < rv.nreads; ++r) {
-          uint32_t o = rv.read_off[r], n = rv.read_cnt[r], ns = 0;
-          for (uint32_t i = o; i < o + n; ++i) ns += rv.rec_sel[i];
-          for (uint32_t i = o; i < o + n; ++i)
-            if (rv.rec_sel[i]) wcount[rv.rec_key[i] >> 1] += 1.0 / ns, twcount += 1.0 / ns;
+      std::string text;
+      // reads [lo, hi) of the job; a batch that overflows a device-side buffer (KR_ERR_CAPACITY: unusually many
+      // table hits or records per read) is resubmitted in halves, as include/krepp_amd.h prescribes
+      std::function<int(size_t, size_t)> run = [&](size_t lo, size_t hi) -> int {
+        std::vector<uint64_t> offs(hi - lo + 1);
+        for (size_t i = lo; i <= hi; ++i) offs[i - lo] = j->offsets[i] - j->offsets[lo];
+        kr_result_view rv;
+        char* txt = nullptr;
+        uint64_t len = 0;
+        int rc = kr_batch_submit(st, j->bases.data() + j->offsets[lo], offs.data(), (uint32_t)(hi - lo),
+                                 KR_BASES_HOST | (place ? KR_TAP_ACCS : 0u));
+        if (!rc) rc = kr_batch_collect(st, &rv);
+        if (rc == KR_ERR_CAPACITY && hi - lo > 1) {
+          const size_t mid = lo + (hi - lo) / 2;
+          rc = run(lo, mid);
+          return rc ? rc : run(mid, hi);
         }
-      }
-      if (!rc && place) {
-        int prev = 0; // batches are joined by the writer (src/krepp.cpp:474-484)
-        rc = kr_place_batch(hx, dix[g], ptree, &rv, j->offsets.data(), nm.data(), &p, tabular, &prev, &txt, &len, nullptr, nullptr);
-      }
+        if (!rc && !place && !summarize) rc = kr_format_dist(hx, &rv, nm.data() + lo, &txt, &len);
+        if (!rc && summarize) { // each read shares one unit among the references it keeps (src/query.cpp:168-170)
+          std::lock_guard<std::mutex> lk(mu);
+          for (uint32_t r = 0; r < rv.nreads; ++r) {
+            uint32_t o = rv.read_off[r], n = rv.read_cnt[r], ns = 0;
+            for (uint32_t i = o; i < o + n; ++i) ns += rv.rec_sel[i];
+            for (uint32_t i = o; i < o + n; ++i)
+              if (rv.rec_sel[i]) wcount[rv.rec_key[i] >> 1] += 1.0 / ns, twcount += 1.0 / ns;
+          }
+        }
+        if (!rc && place) {
+          int prev = (!tabular && !text.empty()) ? 1 : 0; // pieces of a batch are joined here, batches by the writer (src/krepp.cpp:474-484)
+          rc = kr_place_batch(hx, dix[g], ptree, &rv, offs.data(), nm.data() + lo, &p, tabular, &prev, &txt, &len, nullptr, nullptr);
+        }
+        if (!rc && txt) text.append(txt, len);
+        kr_free(txt);
+        return rc;
+      };
+      const int rc = run(0, j->names.size());
       std::lock_guard<std::mutex> lk(mu);
       if (rc) {
         worker_err = kr_last_error();
       } else {
-        if (txt) j->text.assign(txt, len);
-        kr_free(txt);
+        j->text.swap(text);
       }
       j->done = true;
       finished[j->seq] = j;

@@ -416,6 +416,11 @@ def test_cli_dist_end_to_end(capi, po, toy_index_dir, toy_reads, tmp_path):
     r = subprocess.run([exe, "--num-threads", "2", "dist", "-i", toy_index_dir, "-q", str(gz), "-o", str(out)], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout == ""
     assert out.read_text().split("\n", 2)[2] == ox.dist(bases, offs, names, po.params(collect=4))["text"]
+    # a record buffer far too small for the batch: the CLI splits the batch and resubmits (KR_ERR_CAPACITY), same text
+    env = dict(os.environ, KR_DEBUG_CLI_RECORDS="150")
+    r = subprocess.run([exe, "dist", "-i", toy_index_dir, "-q", fq], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split("\n", 2)[2] == ox.dist(bases, offs, names, po.params(collect=4))["text"]
 
 
 def test_cli_dist_summarize(po, toy_index_dir, toy_reads):
