@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""End-to-end time of the `krepp dist` CLI (reader thread -> GPU worker -> ordered writer) on a synthetic FASTQ."""
+import os, subprocess, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from krepp_amd import capi, synth
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+work = tempfile.mkdtemp(prefix="krepp_cli_")
+nwk = os.path.join(root, "tests", "golden", "tree_toy.nwk")
+g = synth.evolve_genomes(open(nwk).read(), 400_000, seed=7)
+tsv = synth.write_genomes(g, os.path.join(work, "g"))
+idx = os.path.join(work, "idx")
+capi.build_index(tsv, idx, nwk=nwk, k=27, w=35, h=11, m=4, r=1, frac=True, num_threads=8)
+fq = os.path.join(work, "reads.fq")
+with open(fq, "wb") as f:
+    done = 0
+    while done < n:
+        m = min(200_000, n - done)
+        b, o, names = synth.sample_reads(g, m, seed=100 + done)
+        r = b.reshape(m, 150)
+        q = b"I" * 150
+        rows = [b"@r%d\n" % (done + i) + r[i].tobytes() + b"\n+\n" + q + b"\n" for i in range(m)]
+        f.write(b"".join(rows))
+        done += m
+exe = os.path.join(root, "krepp_amd", "lib", "krepp")
+for _ in range(2):
+    t = time.time()
+    r = subprocess.run([exe, "dist", "-i", idx, "-q", fq, "-o", os.path.join(work, "out.tsv")], capture_output=True, text=True)
+    dt = time.time() - t
+    print("rc", r.returncode, "reads", n, "seconds %.2f" % dt, "reads/s %.3g" % (n / dt), "output MB %.1f" % (os.path.getsize(os.path.join(work, "out.tsv")) / 1e6))
