@@ -22,6 +22,7 @@
 #include <map>
 #include <memory>
 #include <set>
+#include <omp.h>
 #include <zlib.h>
 
 namespace kr {
@@ -573,9 +574,82 @@ struct kr_fastx {
     return buf[pos++];
   }
 
+  // Refill keeping the unread bytes: move them to the front, read behind them.
+  void fill_keep()
+  {
+    if (eof) return;
+    if (pos > 0) {
+      memmove(buf.data(), buf.data() + pos, end - pos);
+      end -= pos;
+      pos = 0;
+    }
+    while (end < buf.size()) {
+      int n = gzread(f, buf.data() + end, (unsigned)(buf.size() - end));
+      if (n <= 0) {
+        eof = true;
+        break;
+      }
+      end += (size_t)n;
+    }
+  }
+
+  // The common case in bulk: a four-line FASTQ record that lies completely in the buffer, with a clean
+  // sequence line (graphic characters only, none of the record markers) and a quality line of the same
+  // length.  Returns false WITHOUT consuming anything when the record is anything else (FASTA, wrapped lines,
+  // '\r', odd quality, end of input ...): next_record then parses it character by character with kseq's rules.
+  bool fast_fastq(std::string& name, std::vector<uint8_t>& seq_out, long& slen_out)
+  {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      const unsigned char* b = buf.data();
+      size_t p = pos;
+      int mk = last_char;
+      if (mk == 0) {
+        if (p >= end) goto more;
+        mk = b[p++];
+      }
+      if (mk != '@') return false;
+      {
+        const unsigned char* nl1 = p < end ? (const unsigned char*)memchr(b + p, '\n', end - p) : nullptr;
+        if (!nl1) goto more;
+        const size_t s0 = (size_t)(nl1 - b) + 1;
+        const unsigned char* nl2 = s0 < end ? (const unsigned char*)memchr(b + s0, '\n', end - s0) : nullptr;
+        if (!nl2) goto more;
+        const size_t slen = (size_t)(nl2 - b) - s0;
+        const size_t plus = s0 + slen + 1;
+        if (plus >= end) goto more;
+        if (b[plus] != '+') return false;
+        const unsigned char* nl3 = (const unsigned char*)memchr(b + plus, '\n', end - plus);
+        if (!nl3) goto more;
+        const size_t q0 = (size_t)(nl3 - b) + 1;
+        if (q0 + slen >= end) goto more; // the quality characters and the one character kseq reads past them
+        unsigned bad = 0;
+        for (size_t i = 0; i < slen; ++i) {
+          const unsigned c = b[s0 + i];
+          bad |= (unsigned)(c - 33u > 93u) | (unsigned)(c == '>') | (unsigned)(c == '+') | (unsigned)(c == '@');
+        }
+        for (size_t i = 0; i < slen; ++i) bad |= (unsigned)((unsigned)b[q0 + i] - 33u > 94u);
+        if (bad) return false;
+        size_t ne = p; // name: up to the first whitespace
+        while (ne < s0 - 1 && !isspace(b[ne])) ++ne;
+        name.assign((const char*)b + p, ne - p);
+        seq_out.insert(seq_out.end(), b + s0, b + s0 + slen);
+        pos = q0 + slen + 1;
+        last_char = 0;
+        slen_out = (long)slen;
+        return true;
+      }
+    more:
+      if (attempt == 1 || eof || (pos == 0 && end == buf.size())) return false;
+      fill_keep();
+    }
+    return false;
+  }
+
   // returns sequence length, or <0 at end of input / truncated record
   long next_record(std::string& name, std::vector<uint8_t>& seq_out)
   {
+    long fl = 0;
+    if (fast_fastq(name, seq_out, fl)) return fl;
     int c;
     if (last_char == 0) {
       while ((c = getc()) != -1 && c != '>' && c != '@') {
@@ -631,7 +705,7 @@ int kr_fastx_open(const char* path, kr_fastx** out)
   gzbuffer(f, 1 << 20);
   kr_fastx* r = new kr_fastx();
   r->f = f;
-  r->buf.resize(1 << 20);
+  r->buf.resize(4 << 20);
   *out = r;
   return KR_OK;
 }
@@ -680,39 +754,79 @@ void kr_fastx_close(kr_fastx* r)
 
 // report_distances (src/query.cpp:158-196), non-summarize branch.  The selection
 // (multi / filter / dist-max / closest) was already made on the device: rec_sel.
+// "%.5f" of a distance without going through printf: scale, round half away in integers.  printf rounds the
+// exact binary value; the two agree unless d * 1e5 lies within rounding noise of a tie, where printf decides.
+static inline size_t fmt_fixed5(double d, char* out)
+{
+  if (d >= 0.0 && d < 1000.0) {
+    const double sc = d * 100000.0, fl = std::floor(sc), fr = sc - fl;
+    if (std::fabs(fr - 0.5) > 1e-6) {
+      const uint64_t n = (uint64_t)fl + (fr > 0.5 ? 1u : 0u);
+      uint64_t ip = n / 100000u, fp = n % 100000u;
+      char tmp[8];
+      size_t k = 0, o = 0;
+      do {
+        tmp[k++] = (char)('0' + ip % 10u);
+        ip /= 10u;
+      } while (ip);
+      while (k) out[o++] = tmp[--k];
+      out[o++] = '.';
+      for (int q = 4; q >= 0; --q) {
+        out[o + q] = (char)('0' + fp % 10u);
+        fp /= 10u;
+      }
+      return o + 5;
+    }
+  }
+  return (size_t)snprintf(out, 64, "%.5f", d);
+}
+
 int kr_format_dist(const kr_host_index* h, const kr_result_view* rv, const char* const* names, char** text,
                    uint64_t* len)
 {
   if (!h || !rv || !text || !len) return kr::fail(KR_ERR_ARG, "kr_format_dist: null argument");
-  std::string s;
-  s.reserve((size_t)rv->nreads * 48);
-  char num[64];
-  for (uint32_t r = 0; r < rv->nreads; ++r) {
-    const char* id = names ? names[r] : "";
-    uint32_t o = rv->read_off[r], n = rv->read_cnt[r], emitted = 0;
-    for (uint32_t i = o; i < o + n; ++i) {
-      if (!rv->rec_sel[i]) continue;
-      uint32_t se = rv->rec_key[i] >> 1;
-      snprintf(num, sizeof(num), "%.5f", rv->rec_d[i]);
-      s += id;
-      s += '\t';
-      s += kr_host_index_node_name(h, se);
-      s += '\t';
-      s += num;
-      s += '\n';
-      emitted++;
-    }
-    (void)emitted;
-    if (rv->read_na[r]) { // src/query.cpp:173-176
-      s += id;
-      s += "\tNA\tNaN\n";
+  // reads are cut into contiguous ranges, one string per range, joined in order
+  const int nt = rv->nreads >= 4096 ? std::max(1, std::min(omp_get_max_threads(), 16)) : 1;
+  std::vector<std::string> part((size_t)nt);
+#pragma omp parallel for num_threads(nt) schedule(static, 1)
+  for (int t = 0; t < nt; ++t) {
+    const uint32_t r0 = (uint32_t)((uint64_t)rv->nreads * t / nt), r1 = (uint32_t)((uint64_t)rv->nreads * (t + 1) / nt);
+    std::string& s = part[(size_t)t];
+    s.reserve((size_t)(r1 - r0) * 64);
+    char num[64];
+    for (uint32_t r = r0; r < r1; ++r) {
+      const char* id = names ? names[r] : "";
+      const size_t idl = strlen(id);
+      const uint32_t o = rv->read_off[r], n = rv->read_cnt[r];
+      for (uint32_t i = o; i < o + n; ++i) {
+        if (!rv->rec_sel[i]) continue;
+        const char* nm = kr_host_index_node_name(h, rv->rec_key[i] >> 1);
+        const size_t nl = fmt_fixed5(rv->rec_d[i], num);
+        s.append(id, idl);
+        s += '\t';
+        s += nm;
+        s += '\t';
+        s.append(num, nl);
+        s += '\n';
+      }
+      if (rv->read_na[r]) { // src/query.cpp:173-176
+        s.append(id, idl);
+        s += "\tNA\tNaN\n";
+      }
     }
   }
-  char* p = (char*)malloc(s.size() + 1);
+  size_t total = 0;
+  for (auto& s : part) total += s.size();
+  char* p = (char*)malloc(total + 1);
   if (!p) return kr::fail(KR_ERR_NOMEM, "kr_format_dist: out of memory");
-  memcpy(p, s.c_str(), s.size() + 1);
+  size_t at = 0;
+  for (auto& s : part) {
+    memcpy(p + at, s.data(), s.size());
+    at += s.size();
+  }
+  p[total] = 0;
   *text = p;
-  *len = s.size();
+  *len = total;
   return KR_OK;
 }
 

@@ -24,8 +24,8 @@ with open(fq, "wb") as f:
         f.write(b"".join(rows))
         done += m
 exe = os.path.join(root, "krepp_amd", "lib", "krepp")
-for _ in range(2):
+for extra in ([], [], ["--summarize"]):
     t = time.time()
-    r = subprocess.run([exe, "dist", "-i", idx, "-q", fq, "-o", os.path.join(work, "out.tsv")], capture_output=True, text=True)
+    r = subprocess.run([exe, "dist", "-i", idx, "-q", fq, "-o", os.path.join(work, "out.tsv")] + extra, capture_output=True, text=True)
     dt = time.time() - t
-    print("rc", r.returncode, "reads", n, "seconds %.2f" % dt, "reads/s %.3g" % (n / dt), "output MB %.1f" % (os.path.getsize(os.path.join(work, "out.tsv")) / 1e6))
+    print(" ".join(extra) or "rows", "rc", r.returncode, "reads", n, "seconds %.2f" % dt, "reads/s %.3g" % (n / dt), "output MB %.1f" % (os.path.getsize(os.path.join(work, "out.tsv")) / 1e6))
