@@ -286,6 +286,32 @@ def test_single_segment_many_leaves_spill_paths(capi, po, synth, tmp_path, monke
     assert_rows_close(res.rows(), rows_of_oracle(ref))
 
 
+def test_many_leaves_bitmap_spans_several_tiles(capi, po, synth, tmp_path):
+    """2,300 references: 4,600 (leaf, strand) keys = 72 bitmap blocks, more than one 64-lane tile of the ordinal
+    prefix, and level-2 / merge lists longer than a wave (the 10k-genome configuration in the small)."""
+    n = 2300
+    nwk = synth.yule_newick(n, 5)
+    g = synth.evolve_genomes(nwk, 1500, seed=31)
+    tsv = synth.write_genomes(g, str(tmp_path / "g"))
+    (tmp_path / "t.nwk").write_text(nwk)
+    idx = str(tmp_path / "ix")
+    capi.build_index(tsv, idx, nwk=str(tmp_path / "t.nwk"), k=29, w=33, h=13, m=2, r=0, frac=True, num_threads=8)
+    hx = capi.HostIndex(idx)
+    dx = hx.upload(0)
+    ox = po.Index(idx)
+    for length, seed in ((150, 3), (260, 4)):  # one segment (event mode), two segments (merged through the count table)
+        bases, offs, rn = synth.sample_reads(g, 400, seed=seed, length=length)
+        ref = ox.dist(bases, offs, rn, po.params(collect=7))
+        st = dx.stream(max_reads=400, max_bases=len(bases), max_records=400 * 2 * n)
+        st.submit(bases, offs, capi.KR_TAP_ACCS)
+        res = st.collect()
+        acc = ref["accs"][ref["accs"]["passed"] == 1]
+        want = sorted(zip(acc["read"].tolist(), ((acc["se"] << 1) | acc["strand"]).tolist(), [tuple(x[:5]) for x in acc["hist"].tolist()]))
+        got = sorted(zip(res.rec_read.tolist(), res.rec_key.tolist(), [tuple(x) for x in res.rec_hist.tolist()]))
+        assert got == want
+        assert_rows_close(res.rows(), rows_of_oracle(ref))
+
+
 def test_device_brent_vs_oracle(capi, po, toy):
     hx, dx, ox = toy
     rng = np.random.default_rng(31)
