@@ -139,6 +139,7 @@ struct BatchOut {
   uint32_t item_cap;
   uint32_t* rd_it_off;
   uint32_t* rd_it_cnt;
+  uint32_t* long_list;   // [max_reads] reads of several segments, set aside by the first accumulate launch (counters[25])
   // level-2 accumulator scratch, one region per resident wave
   uint32_t* g_planes; // [nwaves][nslots2][np][4]
   uint32_t* g_counts; // [nwaves][nslots2][np]
@@ -325,6 +326,7 @@ struct WaveState {
   uint32_t rec_next, rec_end; // wave-private range of record slots (wave-uniform)
   uint32_t n_l2;              // reads of this wave that used level 2
   uint32_t n_rec;             // records this wave emitted
+  uint32_t ll_next, ll_end;   // wave-private chunk of out.long_list (wave-uniform)
   // event mode (reads of a single segment): leaf updates are appended as 32-bit events
   bool evmode;      // wave-uniform
   bool ev_full;     // wave-uniform: the event buffer overflowed
@@ -553,7 +555,7 @@ struct ReadCursor {
   uint32_t nreads, range, c, tried;
   __device__ __forceinline__ void init(uint32_t* base, uint32_t n, uint32_t home)
   {
-    cur = base, nreads = n, range = (n + kCursors - 1) / kCursors, c = home % kCursors, tried = 0;
+    cur = base, nreads = n, range = (n + kCursors - 1) / kCursors, c = home % kCursors, tried = n ? 0 : kCursors;
   }
   // next chunk [r0, r1); false when every range is used up (wave-uniform)
   __device__ __forceinline__ bool next(uint32_t& r0, uint32_t& r1)
@@ -1411,7 +1413,10 @@ __device__ __forceinline__ void segment_fold(const Acc& A, WaveState& ws, bool& 
   __syncthreads();
 }
 
-template <bool SL>
+// MULTI: the instantiation for reads of several segments.  The single-segment instantiation only notes such
+// reads in out.long_list (the kernel is launched a second time for them): with both in one kernel the merge code's
+// registers cost the common case 5 %.
+template <bool SL, bool MULTI>
 __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams& P, const BatchIn& in,
                                              const BatchOut& out, uint32_t read, const Acc& A, WaveState& ws,
                                              lds_u32* hist_tbl, uint32_t hist_words)
@@ -1429,7 +1434,18 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   const uint64_t tr0 = (P.dbg & 512u) ? __builtin_readcyclecounter() : 0;
   // Event mode: always for reads of one segment; reads of several segments run it per segment and merge the
   // segments' counts in the wave's global count table (debug bit 8192 sends them to the plane tables instead).
-  const bool multi = nkm > (uint64_t)kSegPos;
+  if (!MULTI && nkm > (uint64_t)kSegPos) { // list slots in wave-private chunks of 16 (one shared word serves ~90 M atomics/s)
+    if (ws.ll_next == ws.ll_end) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&out.counters[25], 16u);
+      ws.ll_next = __shfl(base, 0);
+      ws.ll_end = ws.ll_next + 16u;
+    }
+    if (lane == 0) out.long_list[ws.ll_next] = read;
+    ++ws.ll_next;
+    return;
+  }
+  const bool multi = MULTI;
   ws.evmode = !(P.dbg & 8u) && (!multi || !(P.dbg & 8192u));
   bool merged = false; // wave-uniform: the read's segments were merged through the count table
   // A read is processed once; only if its events do not fit (buffer or tables) is it processed a
@@ -1627,7 +1643,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
 
 // NP = th + 1 planes when known at compile time (5: --hdist-th default; the plane loops unroll and the address
 // arithmetic folds), 0 = any threshold.
-template <bool SL, int NP>
+template <bool SL, int NP, bool MULTI>
 __global__ __launch_bounds__(kWave, 4) void kr_acc_kernel_t(DevIndex ix, DevParams P, BatchIn in, BatchOut out)
 {
   if (NP) P.np = NP, P.th = NP - 1;
@@ -1672,6 +1688,7 @@ __global__ __launch_bounds__(kWave, 4) void kr_acc_kernel_t(DevIndex ix, DevPara
   ws.rec_end = 0;
   ws.n_l2 = 0;
   ws.n_rec = 0;
+  ws.ll_next = ws.ll_end = 0;
   ws.evmode = false;
   ws.nev = 0;
   ws.ev = A.planes; // planes + counts are contiguous: kLdsSlots * np * 5 words
@@ -1685,10 +1702,16 @@ __global__ __launch_bounds__(kWave, 4) void kr_acc_kernel_t(DevIndex ix, DevPara
   ws.gtab_cap = out.tab_spill;
   ws.gkt_cap = out.kt_spill;
   ReadCursor rc;
-  rc.init(out.cursors + kCursors * kCursorStride, in.nreads, blockIdx.x);
+  // second launch: the reads the first one set aside (their number is final: kernel boundary)
+  rc.init(out.cursors + (MULTI ? 2u : 1u) * kCursors * kCursorStride, MULTI ? out.counters[25] : in.nreads, blockIdx.x);
   uint32_t r0, r1;
   while (rc.next(r0, r1))
-    for (uint32_t r = r0; r < r1; ++r) process_read<SL>(ix, P, in, out, r, A, ws, (lds_u32*)s_base, kStackCap * 2 + kLdsSlots);
+    for (uint32_t r = r0; r < r1; ++r)
+    {
+      const uint32_t rd = MULTI ? out.long_list[r] : r;
+      if (rd != 0xFFFFFFFFu) process_read<SL, MULTI>(ix, P, in, out, rd, A, ws, (lds_u32*)s_base, kStackCap * 2 + kLdsSlots); // else: unused list slot
+    }
+  for (uint32_t q = ws.ll_next + lane_id(); q < ws.ll_end; q += 64) out.long_list[q] = 0xFFFFFFFFu;
   if (ws.n_l2 && lane_id() == 0) atomicAdd(&out.counters[2], ws.n_l2);
   if (ws.n_rec && lane_id() == 0) atomicAdd(&out.counters[4], ws.n_rec);
 }
@@ -2911,7 +2934,7 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   SA(s->d_bases, max_bases + 256);
   SA(s->d_offsets, (uint64_t)max_reads + 1);
   SA(o.counters, 32);
-  SA(o.cursors, 2 * kCursors * kCursorStride);
+  SA(o.cursors, 3 * kCursors * kCursorStride);
   SA(o.rd_off, max_reads);
   SA(o.rd_cnt, max_reads);
   SA(o.rd_onmers, max_reads);
@@ -2939,6 +2962,7 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   SA(o.items, o.item_cap);
   SA(o.rd_it_off, max_reads);
   SA(o.rd_it_cnt, max_reads);
+  SA(o.long_list, (uint64_t)max_reads + 16ull * s->nwaves);
   o.nslots2 = nslots2;
   o.ev_spill = kEvSpill;
   o.tab_spill = std::min<uint32_t>(nslots2, 4096u);
@@ -3006,7 +3030,7 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
   }
   s->in.nreads = nreads;
   HIP_TRY(hipMemsetAsync(s->out.counters, 0, 128, st));
-  HIP_TRY(hipMemsetAsync(s->out.cursors, 0, 2 * kCursors * kCursorStride * 4, st));
+  HIP_TRY(hipMemsetAsync(s->out.cursors, 0, 3 * kCursors * kCursorStride * 4, st));
   HIP_TRY(hipMemsetAsync(s->out.rec_key, 0, (uint64_t)s->rec_cap * 4, st));
   HIP_TRY(hipMemsetAsync(s->out.rec_sel, 0, (uint64_t)s->rec_cap, st));
   HIP_TRY(hipEventRecord(s->ev[1], st));
@@ -3053,16 +3077,21 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
 #undef KR_LAUNCH
     HIP_TRY(hipEventRecord(s->ev[2], st));
     const uint32_t lds = probe_lds_bytes(s->dp.np, s->out.bm_words);
-    if (single)
-      if (s->dp.np == 5 && !getenv("KR_DEBUG_NP0"))
-        hipLaunchKernelGGL((kr_acc_kernel_t<true, 5>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);
-      else
-        hipLaunchKernelGGL((kr_acc_kernel_t<true, 0>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);
+    const bool np5 = s->dp.np == 5 && !getenv("KR_DEBUG_NP0");
+#define KR_ACC(SLV, NPV)                                                                                                       \
+  do {                                                                                                                       \
+    hipLaunchKernelGGL((kr_acc_kernel_t<SLV, NPV, false>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);        \
+    hipLaunchKernelGGL((kr_acc_kernel_t<SLV, NPV, true>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);         \
+  } while (0)
+    if (single && np5)
+      KR_ACC(true, 5);
+    else if (single)
+      KR_ACC(true, 0);
+    else if (np5)
+      KR_ACC(false, 5);
     else
-      if (s->dp.np == 5)
-        hipLaunchKernelGGL((kr_acc_kernel_t<false, 5>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);
-      else
-        hipLaunchKernelGGL((kr_acc_kernel_t<false, 0>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);
+      KR_ACC(false, 0);
+#undef KR_ACC
   }
   HIP_TRY(hipEventRecord(s->ev[3], st));
   hipLaunchKernelGGL(kr_dedup_clear_kernel, dim3(4096), dim3(256), 0, st, s->out);
