@@ -58,7 +58,9 @@ constexpr int kSegPos = 128;      // k-mer positions per segment = 4 plane words
 constexpr int kPlaneWords = kSegPos / 32;
 constexpr int kMaxLibs = 16;
 constexpr int kStackCap = 256;    // colour work stack (items of 8 B)
-constexpr int kStackUse = kStackCap;
+constexpr int kLeanStack = 192;   // ... of the single-segment accumulate instantiation (128 pushes per step + DAG depth)
+// its stack region also hosts the key bitmap (4 B per word) and the ordinal prefix (1 B per word)
+__host__ __device__ inline uint32_t lean_stack_bytes(uint32_t bm_words) { uint32_t b = 5u * bm_words; b = (b + 15u) & ~15u; return b > kLeanStack * 8u ? b : kLeanStack * 8u; }
 constexpr int kLdsSlots = 64;     // level-1 (LDS) accumulator slots per wave: lane t owns slot t in the epilogue
 constexpr int kLdsProbeMax = 8;   // bounded probe sequence of the level-1 table
 constexpr int kMaxPlanes = KR_MAX_HDIST_TH + 1;
@@ -319,7 +321,8 @@ __device__ __forceinline__ uint32_t tag_lib(uint32_t t) { return (t >> 8) & 15u;
 __device__ __forceinline__ uint32_t tag_hd(uint32_t t) { return (t >> 12) & 31u; }
 
 struct WaveState {
-  lds_u64* stack;   // LDS [kStackCap]: lo | hi << 32
+  lds_u64* stack;   // LDS [stack_cap]: lo | hi << 32
+  uint32_t stack_cap; // entries (wave-uniform)
   uint32_t top;   // wave-uniform
   bool l2;        // this lane sent something to level 2 during this read
   uint32_t err;
@@ -334,6 +337,7 @@ struct WaveState {
   uint32_t ev_cap;  // power of two
   uint32_t ev_words; // words of the region the events and the epilogue's batch arrays share (level-1 planes + counts)
   bool dirty;       // wave-uniform: event mode left data in the level-1 table regions (zeroed on demand)
+  bool lean;        // single-segment instantiation: the key bitmap aliases the (idle) work stack, zeroed per read
   uint32_t* gev;    // global spill: events beyond ev_cap, then table entries beyond the LDS table
   uint32_t gev_cap, gtab_cap, gkt_cap; // spill capacities (events / table entries / keys)
   lds_u32* ev;      // aliases the level-1 planes + counts region
@@ -451,7 +455,7 @@ __device__ __forceinline__ void expand_all(const DevIndex& ix, const Acc& A, Wav
 {
   const uint32_t lane = lane_id();
   while (ws.top > 0) {
-    const uint32_t room = kStackUse - ws.top;
+    const uint32_t room = ws.stack_cap - ws.top;
     const uint32_t n = min(min(64u, ws.top), room);
     if (n == 0) { // cannot make progress: report, drop the rest
       ws.err |= kErrStack;
@@ -1152,6 +1156,10 @@ __device__ __forceinline__ bool finalize_events(const DevIndex& ix, const BatchO
   uint32_t* gtab = ws.gev + ws.gev_cap;
   if (nev) {
     if (nev > ws.ev_cap) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // spilled events are complete
+    if (ws.lean) { // the bitmap aliases the work stack (empty now)
+      for (uint32_t q = lane; q < A.bm_words; q += 64) A.bitmap[q] = 0;
+      WAVE_SYNC();
+    }
     // ---- 1. mark keys, ordinal prefix per 64-bit block
     for (uint32_t t0 = 0; t0 < nev; t0 += 64) {
       const uint32_t i = t0 + lane;
@@ -1434,7 +1442,8 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   const uint64_t tr0 = (P.dbg & 512u) ? __builtin_readcyclecounter() : 0;
   // Event mode: always for reads of one segment; reads of several segments run it per segment and merge the
   // segments' counts in the wave's global count table (debug bit 8192 sends them to the plane tables instead).
-  if (!MULTI && nkm > (uint64_t)kSegPos) { // list slots in wave-private chunks of 16 (one shared word serves ~90 M atomics/s)
+  // set aside for the second launch: list slots in wave-private chunks of 16 (one shared word serves ~90 M atomics/s)
+  auto set_aside = [&]() {
     if (ws.ll_next == ws.ll_end) {
       uint32_t base = 0;
       if (lane == 0) base = atomicAdd(&out.counters[25], 16u);
@@ -1443,17 +1452,20 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
     }
     if (lane == 0) out.long_list[ws.ll_next] = read;
     ++ws.ll_next;
+  };
+  if (!MULTI && (nkm > (uint64_t)kSegPos || (P.dbg & 8u))) {
+    set_aside();
     return;
   }
   const bool multi = MULTI;
-  ws.evmode = !(P.dbg & 8u) && (!multi || !(P.dbg & 8192u));
+  ws.evmode = !MULTI || (!(P.dbg & 8u) && !(P.dbg & 8192u));
   bool merged = false; // wave-uniform: the read's segments were merged through the count table
   // A read is processed once; only if its events do not fit (buffer or tables) is it processed a
   // second time with the plane tables.
   for (;;) {
   if (ws.evmode) {
     ws.dirty = true;
-  } else if (ws.dirty) { // the plane tables must start empty
+  } else if (MULTI && ws.dirty) { // the plane tables must start empty
     WAVE_SYNC();
     A.keys[lane] = 0;
     for (uint32_t i = lane; i < ws.ev_words; i += 64) A.planes[i] = 0;
@@ -1467,7 +1479,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
   bool seg_ok = true; // every segment so far went through the event epilogue
   // the segment before a marker (or the last one) is complete
   auto segment_done = [&]() {
-    if (!ws.evmode) {
+    if (MULTI && !ws.evmode) {
       segment_fold(A, ws, l2_any);
     } else if (multi) {
       seg_ok = seg_ok && !ws.ev_full &&
@@ -1489,7 +1501,7 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
     for (;;) { // markers (reads of more than one segment only) split the tile
       const uint64_t mk = __ballot(valid && marker) & todo;
       const uint64_t upto = mk ? (1ull << (__ffsll((long long)mk) - 1)) - 1ull : ~0ull;
-      if (ws.top > (uint32_t)(kStackUse - 128)) expand_all<SL>(ix, A, ws);
+      if (ws.top + 128u > ws.stack_cap) expand_all<SL>(ix, A, ws);
       expand_step<SL>(ix, A, ws, valid && !marker && ((todo & upto) >> lane & 1ull), se, it.y & 0x1FFFFu);
       if (mk == 0) break;
       expand_all<SL>(ix, A, ws);
@@ -1498,10 +1510,10 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
     }
   }
   expand_all<SL>(ix, A, ws);
-  if (!ws.evmode || multi) segment_done();
+  if (MULTI) segment_done();
   if (ws.err && lane == 0) atomicOr(&out.counters[1], ws.err);
   ws.err = 0;
-  if (!ws.evmode) break;
+  if (MULTI && !ws.evmode) break;
   if (multi) {
     if (seg_ok) { // records from the merged counts, below
       merged = true;
@@ -1526,8 +1538,13 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
     atomicAdd(&out.counters[18], (uint32_t)((tf1 - tr0) >> 6));
   }
   if (fin_ok) return;
+  if (!MULTI) { // does not fit: the second launch has the plane tables
+    set_aside();
+    return;
+  }
   ws.evmode = false; // does not fit: redo the read with the plane tables
   } // redo loop
+  if (!MULTI) return; // (unreachable: keeps the plane code out of this instantiation)
   // records that pass `hdist_min <= 2*hdist_filt+1` (src/query.cpp:101-106,119), ordered by key so
   // that the two strands of a leaf are adjacent
   const uint32_t lim0 = 2u * filt0 + 1u, lim1 = 2u * filt1 + 1u; // u32 wrap keeps "none" = max
@@ -1644,30 +1661,34 @@ __device__ __forceinline__ void process_read(const DevIndex& ix, const DevParams
 // NP = th + 1 planes when known at compile time (5: --hdist-th default; the plane loops unroll and the address
 // arithmetic folds), 0 = any threshold.
 template <bool SL, int NP, bool MULTI>
-__global__ __launch_bounds__(kWave, 4) void kr_acc_kernel_t(DevIndex ix, DevParams P, BatchIn in, BatchOut out)
+__global__ __launch_bounds__(kWave, (MULTI ? 4 : 5)) void kr_acc_kernel_t(DevIndex ix, DevParams P, BatchIn in, BatchOut out)
 {
   if (NP) P.np = NP, P.th = NP - 1;
   // One carve of dynamic LDS (base is 16-byte aligned: no static __shared__ in front):
-  //   stack | level-1 table (keys, planes, counts) | level-2 bitmap | ordinal prefix
+  //   MULTI : stack | level-1 table (keys, planes, counts) | level-2 bitmap | read bitmap | ordinal prefix
+  //   !MULTI: stack (the key bitmap and its prefix alias its start: the stack is empty in the epilogue)
+  //           | table region for the passing keys (the level-1 key slots) | event / batch region
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   KR_LDS uint8_t* s_base = (KR_LDS uint8_t*)s_dyn;
   lds_u64* s_stack = (lds_u64*)s_base;
-  lds_u32* s_tbl = (lds_u32*)(s_base + kStackCap * 8);
+  const uint32_t stack_bytes = MULTI ? kStackCap * 8u : lean_stack_bytes(out.bm_words);
+  lds_u32* s_tbl = (lds_u32*)(s_base + stack_bytes);
 
   Acc A;
   A.np = P.np;
   A.keys = s_tbl;
   A.planes = A.keys + kLdsSlots;
   A.counts = A.planes + kLdsSlots * P.np * kPlaneWords;
-  A.bitmap = A.counts + kLdsSlots * P.np;
-  A.rbitmap = A.bitmap + out.bm_words;
-  A.pre = (lds_u16*)(A.rbitmap + out.bm_words);
+  A.bitmap = MULTI ? A.counts + kLdsSlots * P.np : (lds_u32*)s_base;
+  A.rbitmap = A.bitmap + out.bm_words; // MULTI only
+  A.pre = (lds_u16*)((MULTI ? A.rbitmap : A.bitmap) + out.bm_words);
   A.nslots2 = out.nslots2;
   A.bm_words = out.bm_words;
   const uint64_t w = blockIdx.x;
   A.g_planes = out.g_planes + w * (uint64_t)out.nslots2 * P.np * kPlaneWords;
   A.g_counts = out.g_counts + w * (uint64_t)out.nslots2 * P.np;
   A.g_list = out.g_list + w * (uint64_t)out.g_list_words;
+  if (MULTI)
   { // tables start empty; every read leaves them empty again
     const uint32_t lane = lane_id();
     A.keys[lane] = 0;
@@ -1681,6 +1702,8 @@ __global__ __launch_bounds__(kWave, 4) void kr_acc_kernel_t(DevIndex ix, DevPara
   __syncthreads();
   WaveState ws;
   ws.stack = s_stack;
+  ws.stack_cap = stack_bytes / 8u;
+  ws.lean = !MULTI;
   ws.top = 0;
   ws.l2 = false;
   ws.err = 0;
@@ -1709,7 +1732,7 @@ __global__ __launch_bounds__(kWave, 4) void kr_acc_kernel_t(DevIndex ix, DevPara
     for (uint32_t r = r0; r < r1; ++r)
     {
       const uint32_t rd = MULTI ? out.long_list[r] : r;
-      if (rd != 0xFFFFFFFFu) process_read<SL, MULTI>(ix, P, in, out, rd, A, ws, (lds_u32*)s_base, kStackCap * 2 + kLdsSlots); // else: unused list slot
+      if (rd != 0xFFFFFFFFu) process_read<SL, MULTI>(ix, P, in, out, rd, A, ws, (lds_u32*)s_base, stack_bytes / 4u + kLdsSlots); // else: unused list slot
     }
   for (uint32_t q = ws.ll_next + lane_id(); q < ws.ll_end; q += 64) out.long_list[q] = 0xFFFFFFFFu;
   if (ws.n_l2 && lane_id() == 0) atomicAdd(&out.counters[2], ws.n_l2);
@@ -2481,8 +2504,10 @@ __global__ void kr_relayout_inc(const uint64_t* inc, uint32_t nrows, uint64_t* b
   } while (0)
 
 // dynamic LDS bytes of the probe kernel: stack + probe list + ntouched (+ table)
-uint32_t probe_lds_bytes(uint32_t np, uint32_t bm_words)
+uint32_t probe_lds_bytes(uint32_t np, uint32_t bm_words, bool lean = false)
 {
+  if (lean) // single-segment instantiation: short stack (bitmap aliases it) | key slots | event region
+    return (lean_stack_bytes(bm_words) + kLdsSlots * 4 + kLdsSlots * np * (kPlaneWords + 1) * 4 + 15u) & ~15u;
   uint32_t b = kStackCap * 8;
   b += kLdsSlots * 4 + kLdsSlots * np * kPlaneWords * 4 + kLdsSlots * np * 4 + 2 * bm_words * 4 + bm_words; // two bitmaps + u16 prefix per 2 words
   if (getenv("KR_DEBUG_LDS_PAD")) b += (uint32_t)atoi(getenv("KR_DEBUG_LDS_PAD")); // occupancy experiments
@@ -2824,7 +2849,7 @@ struct kr_stream {
   uint64_t max_bases = 0;
   uint32_t rec_cap = 0, hit_cap = 0;
   uint64_t rec_user_cap = 0; // the caller's max_records (rec_cap adds per-wave chunk slack)
-  uint32_t nwaves = 0;
+  uint32_t nwaves = 0, nwaves_full = 0, nwaves_lean = 0; // per-wave scratch slots; grids of the two accumulate launches
   // device
   uint8_t* d_bases = nullptr;
   uint64_t* d_offsets = nullptr;
@@ -2912,8 +2937,15 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   // resident accumulate waves per CU: LDS-limited, at most 16 by registers (4 per SIMD); reads are handed out
   // dynamically, so a grid that is not fully resident costs nothing
   uint32_t per_cu = std::min<uint32_t>(16u, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words));
-  if (getenv("KR_DEBUG_ACC_WAVES")) per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(getenv("KR_DEBUG_ACC_WAVES")));
-  s->nwaves = (uint32_t)prop.multiProcessorCount * std::max<uint32_t>(1u, per_cu);
+  // the single-segment instantiation has a lean LDS layout and 96 registers: 5 waves per SIMD
+  uint32_t per_cu_lean = std::min<uint32_t>(20u, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words, true));
+  if (getenv("KR_DEBUG_ACC_WAVES")) {
+    per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(getenv("KR_DEBUG_ACC_WAVES")));
+    per_cu_lean = std::min<uint32_t>(per_cu_lean, (uint32_t)atoi(getenv("KR_DEBUG_ACC_WAVES")));
+  }
+  s->nwaves_full = (uint32_t)prop.multiProcessorCount * std::max<uint32_t>(1u, per_cu);
+  s->nwaves_lean = (uint32_t)prop.multiProcessorCount * std::max<uint32_t>(1u, per_cu_lean);
+  s->nwaves = std::max(s->nwaves_full, s->nwaves_lean);
   // default record capacity: up to 2 * leaves per read, at most 16 per read on average
   uint64_t per_read = std::min<uint64_t>(16, std::max<uint64_t>(8, (uint64_t)ix->dix.tree_nnodes + 1));
   uint64_t rc64 = max_records ? max_records : std::max<uint64_t>(1u << 16, (uint64_t)max_reads * per_read);
@@ -3035,7 +3067,6 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
   HIP_TRY(hipMemsetAsync(s->out.rec_sel, 0, (uint64_t)s->rec_cap, st));
   HIP_TRY(hipEventRecord(s->ev[1], st));
   const DevIndex& dix = s->ix->dix;
-  uint32_t grid = std::min(nreads, s->nwaves);
   if (flags & KR_TAP_HITS) {
     if (!s->h_hits) {
       HIP_TRY(hipMalloc((void**)&s->out.hits, (uint64_t)s->hit_cap * sizeof(kr_hit)));
@@ -3076,12 +3107,13 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
 #undef KR_LAUNCH2
 #undef KR_LAUNCH
     HIP_TRY(hipEventRecord(s->ev[2], st));
-    const uint32_t lds = probe_lds_bytes(s->dp.np, s->out.bm_words);
+    const uint32_t lds = probe_lds_bytes(s->dp.np, s->out.bm_words), lds_lean = probe_lds_bytes(s->dp.np, s->out.bm_words, true);
+    const uint32_t grid_lean = std::min(nreads, s->nwaves_lean), grid_full = std::min(nreads, s->nwaves_full);
     const bool np5 = s->dp.np == 5 && !getenv("KR_DEBUG_NP0");
 #define KR_ACC(SLV, NPV)                                                                                                       \
   do {                                                                                                                       \
-    hipLaunchKernelGGL((kr_acc_kernel_t<SLV, NPV, false>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);        \
-    hipLaunchKernelGGL((kr_acc_kernel_t<SLV, NPV, true>), dim3(grid), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);         \
+    hipLaunchKernelGGL((kr_acc_kernel_t<SLV, NPV, false>), dim3(grid_lean), dim3(kWave), lds_lean, st, dix, s->dp, s->in, s->out); \
+    hipLaunchKernelGGL((kr_acc_kernel_t<SLV, NPV, true>), dim3(grid_full), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);  \
   } while (0)
     if (single && np5)
       KR_ACC(true, 5);
