@@ -264,13 +264,18 @@ KR_API void kr_free(void*);
 /* ------------------------------------------------------------------------- */
 /* `krepp place`: IBatch::place_sequences / report_placement (src/query.cpp:198-333), */
 /* TargetIndex::ensure_backbone (src/krepp.cpp:48-64), Tree::map_to_qtree /           */
-/* compute_eff_nchildren (src/phytree.cpp:421-473).  Lineage files (-l) are not built. */
+/* compute_eff_nchildren (src/phytree.cpp:421-473); lineage trees: read_lineages         */
+/* (src/krepp.cpp:37-46), Tree::parse_lineages (src/phytree.cpp:320-369).               */
 /* ------------------------------------------------------------------------- */
 typedef struct kr_place_tree kr_place_tree;
 /* nwk_text == NULL: place on the index's own backbone; otherwise map the index leaves onto the
  * given rooted Newick tree.  kr_place_tree_kinds gives the node_kind array to upload the index
  * with (leaves absent from the placement tree become null nodes, as after map_to_qtree). */
 KR_API int kr_place_tree_create(const kr_host_index*, const char* nwk_text, kr_place_tree** out);
+/* -l/--lineage-file: the placement tree is the taxonomy of a Greengenes/GTDB style lineage file
+ * (`ID <tab> r__Taxon; r__Taxon; ...` per line); its leaves are the reference IDs. */
+KR_API int kr_place_tree_create_lineage(const kr_host_index*, const char* lineage_text, kr_place_tree** out);
+KR_API uint32_t kr_place_tree_nnodes(const kr_place_tree*);
 KR_API void kr_place_tree_free(kr_place_tree*);
 KR_API const uint8_t* kr_place_tree_kinds(const kr_place_tree*);
 
@@ -289,7 +294,13 @@ typedef struct kr_placement {
 KR_API int kr_place_batch(const kr_host_index*, const kr_index*, const kr_place_tree*, const kr_result_view* rv,
                           const uint64_t* offsets, const char* const* names, const kr_params* p, int tabular,
                           int* has_previous, char** text, uint64_t* len, kr_placement** placements, uint64_t* nplacements);
-/* which = 0: text before the batches (jplace opening / tabular header), 1: after (jplace metadata + tree) */
+/* `tabular`: 0 jplace, 1 --tabular, 2 --summarize (no per-read text; feed the placements to
+ * kr_place_summary_add).  place --summarize (src/krepp.cpp:466-471,493-497): `wcount` has
+ * kr_place_tree_nnodes + 1 doubles, zeroed by the caller before the first batch and indexed by edge + 1. */
+KR_API int kr_place_summary_add(const kr_place_tree*, const kr_placement* placements, uint64_t n, double* wcount,
+                                double* twcount);
+KR_API int kr_place_summary_text(const kr_place_tree*, const double* wcount, double twcount, char** text, uint64_t* len);
+/* which = 0: text before the batches (jplace opening / tabular or summary header), 1: after (jplace metadata + tree) */
 KR_API int kr_place_frame(const kr_place_tree*, int which, int tabular, const char* invocation, uint64_t total_qseq,
                           char** text, uint64_t* len);
 

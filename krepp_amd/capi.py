@@ -88,7 +88,8 @@ EXPORTS = [
     "kr_params_default", "kr_stream_create", "kr_stream_destroy", "kr_batch_submit", "kr_batch_wait",
     "kr_batch_collect", "kr_batch_collect_device", "kr_batch_hits", "kr_batch_readtaps",
     "kr_debug_front_end", "kr_debug_brent", "kr_llh_batch", "kr_batch_timing",
-    "kr_place_tree_create", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_frame",
+    "kr_place_tree_create", "kr_place_tree_create_lineage", "kr_place_tree_nnodes", "kr_place_summary_add",
+    "kr_place_summary_text", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_frame",
     "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_format_dist", "kr_free",
     "kr_build_index", "kr_minimizers_cpu", "kr_minimizers_device", "kr_minimizers_free", "kr_last_error", "kr_version",
 ]
@@ -149,6 +150,11 @@ def load():
     lib.kr_batch_timing.argtypes = [vp, C.POINTER(KrTiming)]
     lib.kr_llh_batch.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp, vp]
     lib.kr_place_tree_create.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+    lib.kr_place_tree_create_lineage.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+    lib.kr_place_tree_nnodes.argtypes = [vp]
+    lib.kr_place_tree_nnodes.restype = C.c_uint32
+    lib.kr_place_summary_add.argtypes = [vp, vp, C.c_uint64, vp, C.POINTER(C.c_double)]
+    lib.kr_place_summary_text.argtypes = [vp, vp, C.c_double, C.POINTER(vp), u64p]
     lib.kr_place_tree_free.argtypes = [vp]
     lib.kr_place_tree_free.restype = None
     lib.kr_place_tree_kinds.argtypes = [vp]
@@ -497,12 +503,19 @@ PLACEMENT_DT = np.dtype([("read", "<u4"), ("edge", "<u4"), ("lwr", "<f8"), ("d_l
 class Placer:
     """`krepp place` on one GPU: placement tree + device index (uploaded with the tree's node kinds) + stream."""
 
-    def __init__(self, host_index, nwk_text=None, device=0, tabular=False, max_reads=1 << 16, max_bases=None, **place_opts):
+    def __init__(self, host_index, nwk_text=None, device=0, tabular=False, max_reads=1 << 16, max_bases=None, lineage_text=None,
+                 **place_opts):
+        """tabular: False/0 jplace, True/1 --tabular, 2 --summarize; lineage_text: -l instead of a Newick tree"""
         self.lib = load()
         self.hx = host_index
         self.tabular = tabular
         self.pt = C.c_void_p()
-        check(self.lib.kr_place_tree_create(host_index.h, nwk_text.encode() if nwk_text is not None else None, C.byref(self.pt)))
+        if lineage_text is not None:
+            check(self.lib.kr_place_tree_create_lineage(host_index.h, lineage_text.encode(), C.byref(self.pt)))
+        else:
+            check(self.lib.kr_place_tree_create(host_index.h, nwk_text.encode() if nwk_text is not None else None, C.byref(self.pt)))
+        self.wcount = np.zeros(self.lib.kr_place_tree_nnodes(self.pt) + 1, np.float64)
+        self.twcount = C.c_double(0.0)
         view = KrIndexView()
         C.memmove(C.byref(view), C.byref(host_index.view), C.sizeof(view))
         view.node_kind = self.lib.kr_place_tree_kinds(self.pt)
@@ -533,9 +546,18 @@ class Placer:
         text = C.string_at(txt, ln.value).decode()
         pl = (np.frombuffer(C.string_at(pls, npl.value * PLACEMENT_DT.itemsize), dtype=PLACEMENT_DT).copy()
               if npl.value else np.zeros(0, PLACEMENT_DT))
+        if int(self.tabular) == 2:
+            check(self.lib.kr_place_summary_add(self.pt, pls, npl.value, self.wcount.ctypes.data, C.byref(self.twcount)))
         self.lib.kr_free(txt)
         self.lib.kr_free(pls)
         return text, pl
+
+    def summary(self):
+        txt, ln = C.c_void_p(), C.c_uint64()
+        check(self.lib.kr_place_summary_text(self.pt, self.wcount.ctypes.data, self.twcount, C.byref(txt), C.byref(ln)))
+        s = C.string_at(txt, ln.value).decode()
+        self.lib.kr_free(txt)
+        return s
 
     def close(self):
         if self.pt:

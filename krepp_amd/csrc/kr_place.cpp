@@ -3,7 +3,8 @@
 // Reference: IBatch::report_placement (src/query.cpp:218-333), Minfo::add / get_leq_tau /
 // jukes_cantor_dist (src/query.hpp:139-152,189-197), macros PP_JPLACE_FIELDS / PP_TABULAR_FIELDS
 // (src/query.hpp:202-206), jplace framing (src/krepp.cpp:396-432), placement tree set-up
-// (src/krepp.cpp:48-64, src/phytree.cpp:421-473).
+// (src/krepp.cpp:48-64, src/phytree.cpp:421-473), lineage trees (src/krepp.cpp:37-46,
+// src/phytree.cpp:320-369), --summarize (src/query.cpp:232-233,297-298,322-323; src/krepp.cpp:493-497).
 //
 // Split of work: the GPU has already produced, per read, one record per (leaf, strand) with its
 // histogram, distance and likelihood (kr_scan/acc/llh/select kernels).  Here the host walks each leaf's
@@ -79,6 +80,10 @@ struct Acc { // the fields of Minfo that placement needs
   double jc() const { return -0.75 * log(1 - 4.0 / 3.0 * d); }
 };
 
+void map_leaves(const kr_host_index* hx, const kr_index_view& v, kr_place_tree& pt);
+bool lineage_tree(const char* text, kr_place_tree& pt, std::string& err);
+void finish_tree(kr_place_tree& pt, const kr_index_view& v, bool mapped, bool derive_card);
+
 char* dup_text(const std::string& s, uint64_t* len)
 {
   char* p = (char*)malloc(s.size() + 1);
@@ -113,37 +118,188 @@ int kr_place_tree_create(const kr_host_index* hx, const char* nwk_text, kr_place
   } else { // Tree::map_to_qtree (src/phytree.cpp:421-450)
     std::string err;
     if (!kr::parse_newick(nwk_text, pt->t, err)) return kr::fail(KR_ERR_FORMAT, err);
-    std::map<std::string, uint32_t> name_to_se;
-    for (uint32_t se = 1; se <= nn; ++se)
-      if (v.node_kind[se] == 1) {
-        name_to_se[kr_host_index_node_name(hx, se)] = se;
-        pt->kinds[se] = 0;
-      }
-    for (uint32_t q = 1; q <= pt->t.nnodes(); ++q) {
-      const kr::TreeNode& n = pt->t.nodes[q];
-      if (n.kind == 1 && !n.label.empty()) {
-        auto it = name_to_se.find(n.label);
-        if (it != name_to_se.end()) {
-          pt->idx_to_pt[it->second] = q;
-          pt->kinds[it->second] = 1;
-        }
+    map_leaves(hx, v, *pt);
+  }
+  finish_tree(*pt, v, nwk_text != nullptr, true);
+  *out = pt.release();
+  return KR_OK;
+}
+
+int kr_place_tree_create_lineage(const kr_host_index* hx, const char* lineage_text, kr_place_tree** out)
+{
+  kr::clear_error();
+  if (!hx || !lineage_text || !out) return kr::fail(KR_ERR_ARG, "kr_place_tree_create_lineage: null argument");
+  kr_index_view v;
+  kr_host_index_view(hx, &v);
+  std::unique_ptr<kr_place_tree> pt(new kr_place_tree());
+  std::string err;
+  if (!lineage_tree(lineage_text, *pt, err)) return kr::fail(KR_ERR_FORMAT, err);
+  map_leaves(hx, v, *pt);
+  finish_tree(*pt, v, true, false);
+  *out = pt.release();
+  return KR_OK;
+}
+
+} // extern "C"
+
+namespace {
+
+// Tree::map_to_qtree (src/phytree.cpp:421-450): labelled leaves of the placement tree claim the index
+// leaves of the same name; every other index leaf becomes a null node
+void map_leaves(const kr_host_index* hx, const kr_index_view& v, kr_place_tree& pt)
+{
+  const uint32_t nn = v.tree_nnodes;
+  pt.idx_to_pt.assign(nn + 1, 0);
+  pt.kinds.assign(v.node_kind, v.node_kind + nn + 1);
+  std::map<std::string, uint32_t> name_to_se;
+  for (uint32_t se = 1; se <= nn; ++se)
+    if (v.node_kind[se] == 1) {
+      name_to_se[kr_host_index_node_name(hx, se)] = se;
+      pt.kinds[se] = 0;
+    }
+  for (uint32_t q = 1; q <= pt.t.nnodes(); ++q) {
+    const kr::TreeNode& n = pt.t.nodes[q];
+    if (n.kind == 1 && !n.label.empty()) {
+      auto it = name_to_se.find(n.label);
+      if (it != name_to_se.end()) {
+        pt.idx_to_pt[it->second] = q;
+        pt.kinds[it->second] = 1;
       }
     }
   }
+}
+
+// Tree::parse_lineages (src/phytree.cpp:320-369).  A line is `ID <tab> lineage`; the lineage is a list of
+// `r__Taxon` separated by ';' (a blank after the ';' is dropped first).  Taxa are nodes shared by name, each
+// under the parent it was first seen with; what has no parent at the end hangs below a node "root" (the
+// reference attaches those in hash-map order, this build in order of first appearance).  No branch lengths.
+// Numbering is post-order with children in attachment order (src/phytree.cpp:261-298).  Node::card is summed
+// into the parent at attachment time (src/phytree.hpp:107-116), so a taxon contributes the leaves attached to
+// it SO FAR -- none when it is created; the quirk only feeds the --no-multi tie order and is kept.
+bool lineage_tree(const char* text, kr_place_tree& pt, std::string& err)
+{
+  struct LNode {
+    std::string name;
+    int parent = -1;
+    std::vector<int> kids;
+    uint32_t card = 0;
+  };
+  std::vector<LNode> nd(1);
+  nd[0].name = "root";
+  std::map<std::string, int> by_name;
+  auto hang = [&](int c, int par) {
+    nd[c].parent = par;
+    nd[par].kids.push_back(c);
+    nd[par].card += nd[c].card;
+  };
+  auto line_end = [](char c) { return c == '\n' || c == '\r'; };
+  const char* p = text;
+  while (*p) {
+    const char* e = strchr(p, '\n');
+    std::string raw = e ? std::string(p, e) : std::string(p);
+    p = e ? e + 1 : p + raw.size();
+    std::string line; // regex "; " -> ";" in one pass
+    for (size_t i = 0; i < raw.size(); ++i) {
+      line += raw[i];
+      if (raw[i] == ';' && i + 1 < raw.size() && raw[i + 1] == ' ') ++i;
+    }
+    // two std::getline(.., '\t'): the second fails when nothing follows the first tab
+    const size_t t1 = line.find('\t');
+    if (line.empty() || t1 == std::string::npos || t1 + 1 == line.size()) {
+      err = "Failed to reference to lineage mapping!";
+      return false;
+    }
+    const std::string id = line.substr(0, t1);
+    size_t t2 = line.find('\t', t1 + 1);
+    if (t2 == std::string::npos) t2 = line.size();
+    int parent = -1;
+    for (size_t a = t1 + 1; a < t2;) { // std::getline(lss, taxon, ';'): no piece after a trailing ';'
+      size_t b = line.find(';', a);
+      if (b == std::string::npos || b > t2) b = t2;
+      // regex ".__" -> "": drop every <char>"__" (the char not a line end), left to right, non-overlapping
+      std::string taxon;
+      for (size_t i = a; i < b;) {
+        if (i + 2 < b && !line_end(line[i]) && line[i + 1] == '_' && line[i + 2] == '_')
+          i += 3;
+        else
+          taxon += line[i++];
+      }
+      a = b + 1;
+      if (taxon.empty()) continue;
+      auto it = by_name.find(taxon);
+      if (it == by_name.end()) {
+        nd.emplace_back();
+        const int c = (int)nd.size() - 1;
+        nd[c].name = taxon;
+        if (parent >= 0) hang(c, parent);
+        it = by_name.emplace(taxon, c).first;
+      }
+      parent = it->second;
+    }
+    if (by_name.count(id)) {
+      err = "The same reference appears more than once in the lineage file.";
+      return false;
+    }
+    nd.emplace_back();
+    const int c = (int)nd.size() - 1;
+    nd[c].name = id;
+    nd[c].card = 1;
+    if (parent >= 0) hang(c, parent);
+    by_name.emplace(id, c);
+  }
+  if (nd.size() == 1) {
+    err = "The lineage file is empty.";
+    return false;
+  }
+  for (int c = 1; c < (int)nd.size(); ++c)
+    if (nd[c].parent < 0) hang(c, 0);
+  // post-order numbers without recursion (lineages can be long chains)
+  std::vector<uint32_t> se(nd.size(), 0);
+  std::vector<std::pair<int, size_t>> stack{{0, 0}};
+  uint32_t next = 0;
+  while (!stack.empty()) {
+    auto& top = stack.back();
+    if (top.second < nd[top.first].kids.size()) {
+      const int c = nd[top.first].kids[top.second++];
+      stack.push_back({c, 0});
+    } else {
+      se[top.first] = ++next;
+      stack.pop_back();
+    }
+  }
+  pt.t.nodes.assign(nd.size() + 1, kr::TreeNode{"", NAN, 0, 0});
+  pt.card.assign(nd.size() + 1, 0);
+  for (size_t c = 0; c < nd.size(); ++c) {
+    kr::TreeNode& n = pt.t.nodes[se[c]];
+    n.label = nd[c].name;
+    n.blen = NAN;
+    n.parent = nd[c].parent < 0 ? 0 : se[nd[c].parent];
+    n.kind = nd[c].kids.empty() ? 1 : 2;
+    pt.card[se[c]] = nd[c].card;
+  }
+  return true;
+}
+
+void finish_tree(kr_place_tree& ptr, const kr_index_view& v, bool mapped, bool derive_card)
+{
+  kr_place_tree* pt = &ptr;
+  const uint32_t nn = v.tree_nnodes;
   const uint32_t pn = pt->t.nnodes();
   pt->root = pn; // post-order: the root is numbered last
   pt->kids.assign(pn + 1, {});
   for (uint32_t se = 1; se <= pn; ++se)
     if (pt->t.nodes[se].parent) pt->kids[pt->t.nodes[se].parent].push_back(se);
-  pt->card.assign(pn + 1, 0);
-  for (uint32_t se = 1; se <= pn; ++se) { // children precede parents
-    if (pt->t.nodes[se].kind == 1) pt->card[se] = 1;
-    if (pt->t.nodes[se].parent) pt->card[pt->t.nodes[se].parent] += pt->card[se];
+  if (derive_card) {
+    pt->card.assign(pn + 1, 0);
+    for (uint32_t se = 1; se <= pn; ++se) { // children precede parents
+      if (pt->t.nodes[se].kind == 1) pt->card[se] = 1;
+      if (pt->t.nodes[se].parent) pt->card[pt->t.nodes[se].parent] += pt->card[se];
+    }
   }
   // eff_nchildren: Node::add_children counts every child; after map_to_qtree only children with a
   // mapped leaf below (Tree::compute_eff_nchildren, src/phytree.cpp:452-473)
   pt->eff.assign(pn + 1, 0);
-  if (!nwk_text) {
+  if (!mapped) {
     for (uint32_t se = 1; se <= pn; ++se) pt->eff[se] = (uint32_t)pt->kids[se].size();
   } else {
     std::vector<char> covered(pn + 1, 0);
@@ -157,9 +313,11 @@ int kr_place_tree_create(const kr_host_index* hx, const char* nwk_text, kr_place
     for (uint32_t se = 1; se <= pn; ++se)
       if (covered[se] && pt->t.nodes[se].parent) pt->eff[pt->t.nodes[se].parent]++;
   }
-  *out = pt.release();
-  return KR_OK;
 }
+
+} // namespace
+
+extern "C" {
 
 void kr_place_tree_free(kr_place_tree* pt) { delete pt; }
 const uint8_t* kr_place_tree_kinds(const kr_place_tree* pt) { return pt ? pt->kinds.data() : nullptr; }
@@ -171,7 +329,10 @@ int kr_place_frame(const kr_place_tree* pt, int which, int tabular, const char* 
   std::string o, tree, inv = invocation ? invocation : "";
   nwk_jplace(*pt, pt->root, tree);
   if (which == 0) {
-    if (tabular) // QueryIndex::header_preport (src/krepp.cpp:396-408)
+    if (tabular == 2) // --summarize
+      o = "# software: krepp\tversion: v0.8.3\tinvocation :" + inv + "\n# " + tree +
+          "\nDISTAL_NODE\tEDGE_NUM\tWEIGHTED_COUNT\tSEQUENCE_ABUNDANCE\n";
+    else if (tabular) // QueryIndex::header_preport (src/krepp.cpp:396-408)
       o = "# software: krepp\tversion: v0.8.3\tinvocation :" + inv + "\n# " + tree + "\nSEQ_ID\tDISTAL_NODE\tEDGE_NUM\tLWR\tDIST\n";
     else // begin_jplace (src/krepp.cpp:426-432)
       o = "{\n\t\"version\" : 3,\n\t\"fields\" : [\"edge_num\", \"pendant_length\", \"distal_length\", \"likelihood\", "
@@ -339,11 +500,12 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
     x.read = r, x.edge = en(q), x.lwr = a.lwr, x.d_llh = a.d, x.v_llh = a.v, x.pendant = a.jc() - mid(q), x.distal = mid(q);
     pls.push_back(x);
   };
+  const bool jp = tabular == 0, tb = tabular == 1; // 2: --summarize, no text (the caller sums the placements)
   for (uint32_t r = 0; r < rv->nreads; ++r) {
     ReadPlan& pl = plan[r];
     if (!pl.reported) continue;
     std::string id = names ? names[r] : "";
-    if (!tabular) {
+    if (jp) {
       if (prev) out += ",\n";
       out += "\t\t\t{\"n\" : [\"" + id + "\"], \"p\" : [";
       prev = true;
@@ -351,9 +513,9 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
     if (pl.single) {
       Cand& c = cands[pl.c0];
       record(r, c.se, c.a);
-      if (tabular)
+      if (tb)
         out += id + "\t" + tfields(c.se, c.a) + "\n";
-      else
+      else if (jp)
         out += jfields(c.se, c.a) + "]}";
       continue;
     }
@@ -370,13 +532,13 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
         Cand& c = cands[nd_v[j]];
         c.a.lwr = c.a.lwr / total;
         record(r, c.se, c.a);
-        if (j > 0 && !tabular) out += ",";
-        if (tabular)
+        if (j > 0 && jp) out += ",";
+        if (tb)
           out += id + "\t" + tfields(c.se, c.a) + "\n";
-        else
+        else if (jp)
           out += "\n\t\t\t\t" + jfields(c.se, c.a);
       }
-      if (!tabular) out += "]\n\t\t\t}";
+      if (jp) out += "]\n\t\t\t}";
     } else {
       if (nd_v.size() > 1)
         std::stable_sort(nd_v.begin(), nd_v.end(), [&](size_t l, size_t rr) {
@@ -384,15 +546,15 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
           return cl_ == cr ? cands[l].a.d > cands[rr].a.d : cl_ < cr;
         });
       if (nd_v.empty()) {
-        if (!tabular) out += "]}";
+        if (jp) out += "]}";
         continue;
       }
       Cand& c = cands[nd_v.back()];
       c.a.lwr = c.a.lwr / total;
       record(r, c.se, c.a);
-      if (tabular)
+      if (tb)
         out += id + "\t" + tfields(c.se, c.a) + "\n";
-      else
+      else if (jp)
         out += jfields(c.se, c.a) + "]}";
     }
   }
@@ -405,6 +567,44 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
     if (!pls.empty()) memcpy(*placements, pls.data(), pls.size() * sizeof(kr_placement));
   }
   return KR_OK;
+}
+
+uint32_t kr_place_tree_nnodes(const kr_place_tree* pt) { return pt ? pt->t.nnodes() : 0; }
+
+int kr_place_summary_add(const kr_place_tree* pt, const kr_placement* pls, uint64_t n, double* wcount, double* twcount)
+{ // place --summarize: a read with m placements counts 1/m at each (src/query.cpp:232-233,297-298,322-323);
+  // summed per 512 reads first, as the reference's batches are (src/krepp.cpp:466-471)
+  if (!pt || (!pls && n) || !wcount || !twcount) return kr::fail(KR_ERR_ARG, "kr_place_summary_add: null argument");
+  std::map<uint32_t, double> part;
+  auto flush = [&]() {
+    for (auto& kv : part) *twcount += kv.second, wcount[kv.first] += kv.second;
+    part.clear();
+  };
+  for (uint64_t i = 0; i < n;) {
+    uint64_t j = i;
+    while (j < n && pls[j].read == pls[i].read) ++j;
+    if (i && (pls[i].read >> 9) != (pls[i - 1].read >> 9)) flush();
+    for (uint64_t q = i; q < j; ++q) {
+      if (pls[q].edge + 1 > pt->t.nnodes()) return kr::fail(KR_ERR_ARG, "kr_place_summary_add: edge out of range");
+      part[pls[q].edge + 1] += 1.0 / (double)(j - i);
+    }
+    i = j;
+  }
+  flush();
+  return KR_OK;
+}
+
+int kr_place_summary_text(const kr_place_tree* pt, const double* wcount, double twcount, char** text, uint64_t* len)
+{ // rows of QueryIndex::place_sequences (src/krepp.cpp:493-497), ascending edge number
+  if (!pt || !wcount || !text || !len) return kr::fail(KR_ERR_ARG, "kr_place_summary_text: null argument");
+  std::string o;
+  for (uint32_t se = 1; se <= pt->t.nnodes(); ++se)
+    if (wcount[se] != 0) {
+      const std::string& nm = pt->t.nodes[se].label;
+      o += (nm.empty() ? std::string("NA") : nm) + "\t" + std::to_string(se - 1) + "\t" + f5(wcount[se]) + "\t" + f5(wcount[se] / twcount) + "\n";
+    }
+  *text = dup_text(o, len);
+  return *text ? KR_OK : kr::fail(KR_ERR_NOMEM, "kr_place_summary_text: out of memory");
 }
 
 } // extern "C"

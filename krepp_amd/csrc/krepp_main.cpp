@@ -89,6 +89,8 @@ struct Job {
   std::vector<uint64_t> offsets;
   std::vector<std::string> names;
   std::string text;
+  std::vector<kr_placement> pls; // place --summarize: the placements, `read` = global read number
+  uint64_t first_read = 0;
   bool done = false;
 };
 
@@ -96,9 +98,8 @@ struct Job {
 static int run_query(const Args& a, const std::string& invocation, bool place)
 {
   if (!a.has("--query") || !a.has("--index-dir")) error_exit("dist/place require -q/--query and -i/--index-dir");
-  if (a.has("--lineage-file")) error_exit("-l/--lineage-file is not implemented in this build (use -t or the index's backbone)");
+  if (a.has("--lineage-file") && !place) error_exit("-l/--lineage-file is an option of `place`");
   const bool summarize = a.flag.count("--summarize") && a.flag.at("--summarize");
-  if (summarize && place) error_exit("--summarize is implemented for dist only in this build");
   kr_params p;
   kr_params_default(&p);
   if (a.has("--hdist-th")) p.hdist_th = (uint32_t)atoi(a.get("--hdist-th").c_str());
@@ -109,11 +110,13 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
   }
   if (a.flag.count("--multi")) p.multi = a.flag.at("--multi");
   if (place) p.no_filter = 0; // filter defaults to on for place (src/krepp.cpp:612-615)
-  if (summarize) p.no_filter = 0, p.multi = 1; // "Overrides --no-multi and --no-filter" (src/krepp.cpp:669-672, src/query.cpp:160-171)
+  if (summarize && !place) p.no_filter = 0, p.multi = 1; // "Overrides --no-multi and --no-filter" (src/krepp.cpp:669-672, src/query.cpp:160-171)
   if (a.flag.count("--filter")) p.no_filter = !a.flag.at("--filter");
   if (a.has("--tau")) p.tau = (uint32_t)atoi(a.get("--tau").c_str());
   if (place && p.hdist_th < p.tau) error_exit("The threshold tau must be less than HD threshold --hdist-th!");
-  const bool tabular = a.flag.count("--tabular") && a.flag.at("--tabular");
+  const bool tabular_flag = a.flag.count("--tabular") && a.flag.at("--tabular");
+  // place: 0 jplace, 1 tabular, 2 summary (--summarize wins over --tabular: src/krepp.cpp:401-405,441,467,493)
+  const int tabular = (place && summarize) ? 2 : (tabular_flag ? 1 : 0);
   int ngpus = a.has("--gpus") ? atoi(a.get("--gpus").c_str()) : 1;
   int dev0 = a.has("--device") ? atoi(a.get("--device").c_str()) : 0;
   if (ngpus < 1) ngpus = 1;
@@ -130,18 +133,26 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
   kr_host_index_view(hx, &view);
   kr_place_tree* ptree = nullptr;
   if (place) {
-    std::string nwk_text;
-    if (a.has("--nwk-file")) {
-      FILE* tf = fopen(a.get("--nwk-file").c_str(), "rb");
-      if (!tf) error_exit("Error opening " + a.get("--nwk-file"));
+    auto slurp = [&](const std::string& path) {
+      std::string text;
+      FILE* tf = fopen(path.c_str(), "rb");
+      if (!tf) error_exit("Error opening " + path);
       char buf[65536];
       size_t n;
-      while ((n = fread(buf, 1, sizeof(buf), tf)) > 0) nwk_text.append(buf, n);
+      while ((n = fread(buf, 1, sizeof(buf), tf)) > 0) text.append(buf, n);
       fclose(tf);
+      return text;
+    };
+    if (a.has("--lineage-file")) { // src/krepp.cpp:742-744: -l takes precedence over -t and the backbone
+      if (kr_place_tree_create_lineage(hx, slurp(a.get("--lineage-file")).c_str(), &ptree)) error_exit(kr_last_error());
+      fprintf(stderr, "Placing given sequences on the taxonomic lineage...\n");
+    } else {
+      std::string nwk_text;
+      if (a.has("--nwk-file")) nwk_text = slurp(a.get("--nwk-file"));
+      if (kr_place_tree_create(hx, a.has("--nwk-file") ? nwk_text.c_str() : nullptr, &ptree)) error_exit(kr_last_error());
+      fprintf(stderr, "Placing given sequences on the backbone tree...\n");
     }
-    if (kr_place_tree_create(hx, a.has("--nwk-file") ? nwk_text.c_str() : nullptr, &ptree)) error_exit(kr_last_error());
     view.node_kind = kr_place_tree_kinds(ptree); // leaves absent from the placement tree become null nodes
-    fprintf(stderr, "Placing given sequences on the backbone tree...\n");
   }
   std::vector<kr_index*> dix(ngpus, nullptr);
   for (int g = 0; g < ngpus; ++g)
@@ -198,6 +209,7 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
       std::vector<const char*> nm(j->names.size());
       for (size_t i = 0; i < nm.size(); ++i) nm[i] = j->names[i].c_str();
       std::string text;
+      std::vector<kr_placement> pls;
       // reads [lo, hi) of the job; a batch that overflows a device-side buffer (KR_ERR_CAPACITY: unusually many
       // table hits or records per read) is resubmitted in halves, as include/krepp_amd.h prescribes
       std::function<int(size_t, size_t)> run = [&](size_t lo, size_t hi) -> int {
@@ -215,7 +227,7 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
           return rc ? rc : run(mid, hi);
         }
         if (!rc && !place && !summarize) rc = kr_format_dist(hx, &rv, nm.data() + lo, &txt, &len);
-        if (!rc && summarize) { // each read shares one unit among the references it keeps (src/query.cpp:168-170)
+        if (!rc && summarize && !place) { // each read shares one unit among the references it keeps (src/query.cpp:168-170)
           std::lock_guard<std::mutex> lk(mu);
           for (uint32_t r = 0; r < rv.nreads; ++r) {
             uint32_t o = rv.read_off[r], n = rv.read_cnt[r], ns = 0;
@@ -226,7 +238,15 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
         }
         if (!rc && place) {
           int prev = (!tabular && !text.empty()) ? 1 : 0; // pieces of a batch are joined here, batches by the writer (src/krepp.cpp:474-484)
-          rc = kr_place_batch(hx, dix[g], ptree, &rv, offs.data(), nm.data() + lo, &p, tabular, &prev, &txt, &len, nullptr, nullptr);
+          kr_placement* pp = nullptr;
+          uint64_t npp = 0;
+          rc = kr_place_batch(hx, dix[g], ptree, &rv, offs.data(), nm.data() + lo, &p, tabular, &prev, &txt, &len,
+                              tabular == 2 ? &pp : nullptr, tabular == 2 ? &npp : nullptr);
+          for (uint64_t i = 0; i < npp; ++i) {
+            pp[i].read = (uint32_t)(j->first_read + lo + pp[i].read);
+            pls.push_back(pp[i]);
+          }
+          kr_free(pp);
         }
         if (!rc && txt) text.append(txt, len);
         kr_free(txt);
@@ -238,6 +258,7 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
         worker_err = kr_last_error();
       } else {
         j->text.swap(text);
+        j->pls.swap(pls);
       }
       j->done = true;
       finished[j->seq] = j;
@@ -249,6 +270,11 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
   for (int g = 0; g < ngpus; ++g) workers.emplace_back(worker, g);
 
   bool jplace_prev = false;
+  // place --summarize: counts per placement-tree node, summed by the writer in input order; placements of a
+  // 512-read group that straddles two jobs wait in `carry` (the groups are the reference's batches)
+  std::vector<double> pwcount(place ? kr_place_tree_nnodes(ptree) + 1 : 0, 0.0);
+  double ptwcount = 0;
+  std::vector<kr_placement> carry;
   std::thread writer([&] {
     uint64_t next = 0;
     for (;;) {
@@ -262,7 +288,19 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
         j = it->second;
         finished.erase(it);
       }
-      if (place && !tabular) {
+      if (tabular == 2) {
+        const uint32_t end_group = (uint32_t)(j->first_read + j->names.size()) >> 9;
+        carry.insert(carry.end(), j->pls.begin(), j->pls.end());
+        size_t cut = carry.size();
+        if ((j->first_read + j->names.size()) & 511u)
+          while (cut > 0 && (carry[cut - 1].read >> 9) == end_group) --cut;
+        if (kr_place_summary_add(ptree, carry.data(), cut, pwcount.data(), &ptwcount)) {
+          std::lock_guard<std::mutex> lk(mu);
+          worker_err = kr_last_error();
+          return;
+        }
+        carry.erase(carry.begin(), carry.begin() + cut);
+      } else if (place && !tabular) {
         if (!j->text.empty()) {
           if (jplace_prev) fputs(",\n", out);
           fwrite(j->text.data(), 1, j->text.size(), out);
@@ -294,6 +332,7 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
       j->offsets.resize(r1 - r0 + 1);
       for (uint32_t i = r0; i <= r1; ++i) j->offsets[i - r0] = b.offsets[i] - b.offsets[r0];
       for (uint32_t i = r0; i < r1; ++i) j->names.emplace_back(b.names[i]);
+      j->first_read = nreads_total;
       nreads_total += r1 - r0;
       {
         std::unique_lock<std::mutex> lk(mu);
@@ -319,8 +358,17 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
   cv_done.notify_all();
   writer.join();
   if (!worker_err.empty()) error_exit(worker_err);
-  if (summarize) // src/krepp.cpp:388-393 (ascending colour id instead of hash-map order)
+  if (summarize && !place) // src/krepp.cpp:388-393 (ascending colour id instead of hash-map order)
     for (auto& kv : wcount) fprintf(out, "%s\t%.5f\t%.5f\n", kr_host_index_node_name(hx, kv.first), kv.second, kv.second / twcount);
+  if (tabular == 2) { // src/krepp.cpp:493-497
+    char* t = nullptr;
+    uint64_t l = 0;
+    if (kr_place_summary_add(ptree, carry.data(), carry.size(), pwcount.data(), &ptwcount) ||
+        kr_place_summary_text(ptree, pwcount.data(), ptwcount, &t, &l))
+      error_exit(kr_last_error());
+    fwrite(t, 1, l, out);
+    kr_free(t);
+  }
   if (place) {
     char* t = nullptr;
     uint64_t l = 0;

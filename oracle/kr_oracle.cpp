@@ -230,6 +230,8 @@ struct TNode {
   std::vector<int> children;
   uint32_t card = 0;          // leaves below (Node::add_children, src/phytree.hpp:107-116)
   uint32_t eff_nchildren = 0; // children with a mapped leaf below (Tree::compute_eff_nchildren)
+  bool is_taxon = false;      // Node::set_rank (src/phytree.hpp:90-94): taxa of a lineage tree and its root
+  std::string rank;
 };
 
 struct Tree {
@@ -379,6 +381,119 @@ struct Tree {
     atter = 0;
     nnodes = 0;
     return parse(root, el);
+  }
+
+  // Tree::parse_lineages (src/phytree.cpp:320-369): taxonomy as a tree.  One line per reference:
+  // ID <tab> lineage, taxa separated by ';' (after "; " -> ";"), each "r__Name".  A taxon keeps the parent
+  // it was first seen under; parentless nodes are hung below "root" at the end -- the reference does that in
+  // hash-map order, here in order of first appearance.  Node::card is added to the parent when the child is
+  // attached (Node::add_children, src/phytree.hpp:107-116), i.e. before a taxon has received its own
+  // children: restated as is.  Numbering: post-order, children in attachment order (:261-298).
+  static std::string strip_rank_prefixes(const std::string& t)
+  { // std::regex_replace(taxon, std::regex(".__"), ""): every non-overlapping <any char but a line end>"__"
+    std::string o;
+    size_t i = 0;
+    while (i < t.size()) {
+      if (i + 2 < t.size() && t[i] != '\n' && t[i] != '\r' && t[i + 1] == '_' && t[i + 2] == '_')
+        i += 3;
+      else
+        o += t[i++];
+    }
+    return o;
+  }
+  static std::string rank_of(const std::string& t)
+  { // std::regex_replace(taxon, std::regex("__.*"), ""): '.' stops at a line end
+    std::string o;
+    size_t i = 0;
+    while (i < t.size()) {
+      if (i + 1 < t.size() && t[i] == '_' && t[i + 1] == '_') {
+        i += 2;
+        while (i < t.size() && t[i] != '\n' && t[i] != '\r') ++i;
+      } else
+        o += t[i++];
+    }
+    return o;
+  }
+  void attach(int child, int parent)
+  { // Node::set_parent + add_children (src/phytree.hpp:95-116)
+    if (parent < 0) return;
+    nodes[child].parent = parent;
+    nodes[parent].children.push_back(child);
+    nodes[parent].card += nodes[child].card;
+    nodes[parent].is_leaf = false;
+  }
+  void number_post_order(int nd)
+  {
+    for (int c : nodes[nd].children) number_post_order(c);
+    nnodes++;
+    nodes[nd].se = nnodes;
+    se_to_node.push_back(nd);
+  }
+  bool parse_lineages(const std::string& text)
+  {
+    root = new_node();
+    nodes[root].name = "root";
+    nodes[root].is_leaf = true; // until something is attached
+    nodes[root].is_taxon = true;
+    nodes[root].rank = "root";
+    nnodes = 0;
+    std::map<std::string, int> taxon_to_node;
+    std::vector<int> order; // creation order of the map's nodes
+    std::istringstream in(text);
+    std::string line;
+    while (std::getline(in, line)) {
+      { // std::regex_replace(line, std::regex("; "), ";"): one left-to-right pass
+        std::string o;
+        for (size_t q = 0; q < line.size(); ++q) {
+          o += line[q];
+          if (line[q] == ';' && q + 1 < line.size() && line[q + 1] == ' ') ++q;
+        }
+        line.swap(o);
+      }
+      size_t tab = line.find('\t');
+      if (line.empty() || tab == std::string::npos || tab + 1 == line.size()) {
+        err = "Failed to reference to lineage mapping!";
+        return false;
+      }
+      std::string name = line.substr(0, tab), lineage = line.substr(tab + 1);
+      size_t tab2 = lineage.find('\t');
+      if (tab2 != std::string::npos) lineage.resize(tab2);
+      std::istringstream lss(lineage);
+      std::string taxon;
+      int parent = -1;
+      while (std::getline(lss, taxon, ';')) {
+        std::string rank = rank_of(taxon);
+        taxon = strip_rank_prefixes(taxon);
+        if (taxon.empty()) continue;
+        if (!taxon_to_node.count(taxon)) {
+          int nd = new_node();
+          nodes[nd].name = taxon;
+          nodes[nd].is_leaf = false;
+          nodes[nd].card = 0;
+          attach(nd, parent);
+          nodes[nd].is_taxon = true;
+          nodes[nd].rank = rank;
+          taxon_to_node[taxon] = nd;
+          order.push_back(nd);
+        }
+        parent = taxon_to_node[taxon];
+      }
+      if (taxon_to_node.count(name)) {
+        err = "The same reference appears more than once in the lineage file.";
+        return false;
+      }
+      int nd = new_node();
+      nodes[nd].name = name;
+      nodes[nd].is_leaf = true;
+      nodes[nd].card = 1;
+      attach(nd, parent);
+      taxon_to_node[name] = nd;
+      order.push_back(nd);
+    }
+    for (int nd : order)
+      if (nodes[nd].parent < 0) attach(nd, root);
+    number_post_order(root);
+    return true;
   }
 
   // Node::generate_tree (src/phytree.cpp:217-253): balanced tree by recursive
@@ -808,6 +923,7 @@ struct Worker {
   // --summarize (src/query.cpp:160-171): reference -> weighted read count
   bool summarize = false;
   std::map<uint32_t, double> node_to_wcount;
+  std::map<uint32_t, double> pnode_to_wcount; // place --summarize: se of the placement-tree node -> count
 
   Worker(const ko_index* ix_, const ko_params& p_)
     : ix(ix_), p(p_)
@@ -949,13 +1065,15 @@ struct Worker {
     int nd_pp = pnode(nd_closest);
     Minfo* mi_pp = mi_closest;
     mi_pp->chisq = 0;
-    if (!tabular) {
+    if (!tabular && !summarize) {
       if (has_previous) text += ",\n";
       text += "\t\t\t{\"n\" : [\"" + id + "\"], \"p\" : [";
     }
     if (node_to_minfo.size() == 1) {
       record(nd_pp, *mi_pp);
-      if (tabular)
+      if (summarize)
+        pnode_to_wcount[pt.nodes[nd_pp].se] += 1.0;
+      else if (tabular)
         text += id + "\t" + tabular_fields(nd_pp, *mi_pp) + "\n";
       else
         text += jplace_fields(nd_pp, *mi_pp) + "]}";
@@ -972,8 +1090,12 @@ struct Worker {
       double denom = 1.0;
       int nd_parent = nd_curr;
       while ((nd_parent = pt.nodes[nd_parent].parent) >= 0) {
-        // check_taxon() is false without a lineage file (-l is not restated): always the else branch
-        denom /= pt.nodes[nd_parent].eff_nchildren;
+        // src/query.cpp:257-262.  Keys of node_to_minfo are leaves, which never carry a rank: the first
+        // branch cannot fire even on a lineage tree (kept for the record).
+        if (pt.nodes[nd_parent].is_taxon && pt.nodes[nd_curr].is_taxon)
+          denom = 1.0;
+        else
+          denom /= pt.nodes[nd_parent].eff_nchildren;
         if (!pp_map.count(nd_parent)) {
           owned.emplace_back(new Minfo(p.hdist_th));
           pp_map[nd_parent] = owned.back().get();
@@ -1007,13 +1129,17 @@ struct Worker {
         Minfo* mi = pp_map[nd];
         mi->lwr = mi->lwr / total_lwr;
         record(nd, *mi);
+        if (summarize) {
+          pnode_to_wcount[pt.nodes[nd].se] += 1.0 / nd_v.size();
+          continue;
+        }
         if (i > 0 && !tabular) text += ",";
         if (tabular)
           text += id + "\t" + tabular_fields(nd, *mi) + "\n";
         else
           text += "\n\t\t\t\t" + jplace_fields(nd, *mi);
       }
-      if (!tabular) text += "]\n\t\t\t}";
+      if (!tabular && !summarize) text += "]\n\t\t\t}";
     } else {
       if (nd_v.size() > 1) {
         std::stable_sort(nd_v.begin(), nd_v.end(), [&](int lhs, int rhs) {
@@ -1022,14 +1148,16 @@ struct Worker {
         });
       }
       if (nd_v.empty()) { // the reference dereferences nd_v.back() here (UB); nothing can be reported
-        if (!tabular) text += "]}";
+        if (!tabular && !summarize) text += "]}";
         return true;
       }
       int nd = nd_v.back();
       Minfo* mi = pp_map[nd];
       mi->lwr = mi->lwr / total_lwr;
       record(nd, *mi);
-      if (tabular)
+      if (summarize)
+        pnode_to_wcount[pt.nodes[nd].se] += 1.0;
+      else if (tabular)
         text += id + "\t" + tabular_fields(nd, *mi) + "\n";
       else
         text += jplace_fields(nd, *mi) + "]}";
@@ -1485,6 +1613,7 @@ uint64_t ko_xur64(uint64_t h) { return xur64_hash(h); }
 } // extern "C"
 
 namespace {
+void map_to_qtree(ko_index* ix, Tree&& q);
 void compute_card(Tree& t, int nd)
 {
   TNode& n = t.nodes[nd];
@@ -1537,14 +1666,44 @@ int ko_index_set_placement_tree(ko_index* ix, const char* nwk_text, char* err, i
     for (uint32_t se = 1; se <= nn; ++se) {
       int nd = ix->tree.get_node(se);
       if (nd >= 0 && ix->tree.nodes[nd].is_leaf) ix->se_to_pnode[se] = nd;
+      ix->kind[se] = nd < 0 ? 0 : (ix->tree.nodes[nd].is_leaf ? 1 : 2); // undo an earlier mapping onto another tree
     }
     for (auto& n : ix->ptree.nodes) n.eff_nchildren = (uint32_t)n.children.size(); // Node::add_children
-  } else { // Tree::map_to_qtree (src/phytree.cpp:421-450) + compute_eff_nchildren (:452-473)
+  } else {
     Tree q;
     if (!q.load(nwk_text)) {
       set_err(err, errlen, q.err);
       return -1;
     }
+    map_to_qtree(ix, std::move(q));
+  }
+  compute_card(ix->ptree, ix->ptree.root);
+  ix->have_ptree = true;
+  return 0;
+}
+
+// TargetIndex::read_lineages (src/krepp.cpp:37-46): the placement tree is the taxonomy of a lineage file
+int ko_index_set_lineage_tree(ko_index* ix, const char* lineage_text, char* err, int errlen)
+{
+  ix->se_to_pnode.assign(ix->tree.nnodes + 1, -1);
+  Tree q;
+  if (!lineage_text || !q.parse_lineages(lineage_text)) {
+    set_err(err, errlen, lineage_text ? q.err : "Error opening the lineage file");
+    return -1;
+  }
+  map_to_qtree(ix, std::move(q)); // Node::card stays as parse_lineages left it
+  ix->have_ptree = true;
+  return 0;
+}
+
+} // extern "C"
+
+namespace {
+// Tree::map_to_qtree (src/phytree.cpp:421-450) + compute_eff_nchildren (:452-473)
+void map_to_qtree(ko_index* ix, Tree&& q)
+{
+  const uint32_t nn = ix->tree.nnodes;
+  {
     std::map<std::string, uint32_t> name_to_se;
     for (uint32_t se = 1; se <= nn; ++se) {
       int nd = ix->tree.get_node(se);
@@ -1576,10 +1735,10 @@ int ko_index_set_placement_tree(ko_index* ix, const char* nwk_text, char* err, i
       if (covered[nd] && q.nodes[nd].parent >= 0) q.nodes[q.nodes[nd].parent].eff_nchildren++;
     ix->ptree = std::move(q);
   }
-  compute_card(ix->ptree, ix->ptree.root);
-  ix->have_ptree = true;
-  return 0;
 }
+} // namespace
+
+extern "C" {
 
 // QueryIndex::place_sequences (src/krepp.cpp:434-504): batch texts joined with ",\n" (jplace) or
 // concatenated (tabular); within a batch IBatch::place_sequences (src/query.cpp:198-216).
@@ -1633,13 +1792,52 @@ int ko_place_batch(const ko_index* ix, const char* bases, const uint64_t* offset
   return 0;
 }
 
+// place --summarize (src/query.cpp:232-233,297-298,322-323; src/krepp.cpp:466-471,493-497): per placement-tree
+// node the number of reads placed there, a read with n placements counting 1/n for each.  Batches of 512 reads
+// summed in input order; rows in ascending edge number (the reference's row order is a hash map's).
+int ko_place_summarize(const ko_index* ix, const char* bases, const uint64_t* offsets, uint32_t nreads, const ko_params* p,
+                       ko_result* out)
+{
+  memset(out, 0, sizeof(*out));
+  if (!ix->have_ptree || p->hdist_th > 16) return -1;
+  const uint32_t B = 512;
+  std::map<uint32_t, double> total;
+  double twcount = 0;
+  for (uint32_t r0 = 0; r0 < nreads; r0 += B) {
+    Worker w(ix, *p);
+    w.place_mode = true;
+    w.summarize = true;
+    ko_readinfo ri;
+    for (uint32_t r = r0; r < std::min(nreads, r0 + B); ++r) {
+      w.read_ix = r;
+      memset(&ri, 0, sizeof(ri));
+      w.run_read(bases + offsets[r], offsets[r + 1] - offsets[r], nullptr, ri);
+    }
+    for (auto& kv : w.pnode_to_wcount) twcount += kv.second, total[kv.first] += kv.second;
+    add_counters(out->counters, w.c);
+  }
+  std::string text;
+  for (auto& kv : total) {
+    const TNode& n = ix->ptree.nodes[ix->ptree.get_node(kv.first)];
+    text += (n.name.empty() ? std::string("NA") : n.name) + "\t" + std::to_string(kv.first - 1) + "\t" + Worker::f5(kv.second) + "\t" +
+            Worker::f5(kv.second / twcount) + "\n";
+  }
+  out->text_len = text.size();
+  out->text = (char*)malloc(text.size() + 1);
+  memcpy(out->text, text.c_str(), text.size() + 1);
+  return 0;
+}
+
 char* ko_place_frame(const ko_index* ix, int which, int tabular, const char* invocation, uint64_t total_qseq)
 {
   std::string o, tree;
   nwk_jplace(ix->ptree, ix->ptree.root, tree);
   std::string inv = invocation ? invocation : "";
   if (which == 0) {
-    if (tabular) // QueryIndex::header_preport (src/krepp.cpp:396-408)
+    if (tabular == 2) // --summarize
+      o = "# software: krepp\tversion: v0.8.3\tinvocation :" + inv + "\n# " + tree +
+          "\nDISTAL_NODE\tEDGE_NUM\tWEIGHTED_COUNT\tSEQUENCE_ABUNDANCE\n";
+    else if (tabular) // QueryIndex::header_preport (src/krepp.cpp:396-408)
       o = "# software: krepp\tversion: v0.8.3\tinvocation :" + inv + "\n# " + tree + "\nSEQ_ID\tDISTAL_NODE\tEDGE_NUM\tLWR\tDIST\n";
     else // begin_jplace (src/krepp.cpp:426-432)
       o = "{\n\t\"version\" : 3,\n\t\"fields\" : [\"edge_num\", \"pendant_length\", \"distal_length\", \"likelihood\", "

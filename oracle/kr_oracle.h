@@ -155,10 +155,17 @@ void ko_result_free(ko_result*);
 /* `krepp place` (src/krepp.cpp:434-504, src/query.cpp:198-333).  ko_index_set_placement_tree:
  * nwk == NULL uses the index's own backbone (TargetIndex::ensure_backbone, src/krepp.cpp:48-64),
  * otherwise the index leaves are mapped onto the given tree (Tree::map_to_qtree,
- * src/phytree.cpp:421-450).  Lineage files (-l) are not restated.  The text returned by
+ * src/phytree.cpp:421-450).  ko_index_set_lineage_tree builds the placement tree from a lineage file
+ * instead (-l; TargetIndex::read_lineages src/krepp.cpp:37-46, Tree::parse_lineages
+ * src/phytree.cpp:320-369).  The text returned by
  * ko_place_batch is the concatenation of the reference's per-batch streams (512-read batches)
  * joined as QueryIndex::place_sequences joins them; ko_place_frame gives header / footer. */
 int ko_index_set_placement_tree(ko_index*, const char* nwk_text, char* err, int errlen);
+int ko_index_set_lineage_tree(ko_index*, const char* lineage_text, char* err, int errlen);
+/* place --summarize: out->text = DISTAL_NODE\tEDGE_NUM\tWEIGHTED_COUNT\tSEQUENCE_ABUNDANCE rows;
+ * ko_place_frame(which = 0, tabular = 2) gives its header */
+int ko_place_summarize(const ko_index*, const char* bases, const uint64_t* offsets, uint32_t nreads, const ko_params* p,
+                       ko_result* out);
 int ko_place_batch(const ko_index*, const char* bases, const uint64_t* offsets, const char* const* names,
                    uint32_t nreads, const ko_params* p, int tabular, ko_result* out);
 /* which: 0 = text before the batches, 1 = text after them; caller frees with free() */

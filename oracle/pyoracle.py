@@ -83,6 +83,8 @@ def lib():
         l.ko_result_free.argtypes = [C.POINTER(KoResult)]
         l.ko_dist_summarize.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(KoParams), C.POINTER(KoResult)]
         l.ko_index_set_placement_tree.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int]
+        l.ko_index_set_lineage_tree.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int]
+        l.ko_place_summarize.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(KoParams), C.POINTER(KoResult)]
         l.ko_place_batch.argtypes = [vp, vp, vp, vp, C.c_uint32, C.POINTER(KoParams), C.c_int, C.POINTER(KoResult)]
         l.ko_place_frame.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_uint64]
         l.ko_place_frame.restype = vp
@@ -215,6 +217,24 @@ class Index:
         rc = self.l.ko_index_set_placement_tree(self.h, nwk_text.encode() if nwk_text is not None else None, err, 512)
         if rc:
             raise RuntimeError("oracle: " + err.value.decode())
+
+    def set_lineage_tree(self, lineage_text):
+        err = C.create_string_buffer(512)
+        rc = self.l.ko_index_set_lineage_tree(self.h, lineage_text.encode(), err, 512)
+        if rc:
+            raise RuntimeError("oracle: " + err.value.decode())
+
+    def place_summarize(self, bases, offsets, p=None):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        p = p or params(no_filter=0)
+        res = KoResult()
+        rc = self.l.ko_place_summarize(self.h, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, C.byref(p), C.byref(res))
+        if rc:
+            raise RuntimeError(f"oracle ko_place_summarize rc={rc}")
+        txt = C.string_at(res.text, res.text_len).decode() if res.text_len else ""
+        self.l.ko_result_free(C.byref(res))
+        return txt
 
     def place(self, bases, offsets, names=None, p=None, tabular=False):
         bases = np.ascontiguousarray(bases, dtype=np.uint8)

@@ -107,3 +107,140 @@ def test_cli_place_end_to_end(po, toy_index_dir, toy_reads, tmp_path):
     wt = ox.place(bases, offs, names, po.params(no_filter=0, multi=0, tau=1), tabular=True)
     inv = f"{exe} place -i {toy_index_dir} -q {fq} --tabular --no-multi --tau 1"
     assert r.stdout == ox.place_frame(0, True, inv) + wt["text"]
+
+
+# ---- lineage trees (-l) and place --summarize ------------------------------------------------
+
+LINEAGES_SMALL = (
+    "G1\tk__B; p__P1; c__C1; s__\n"
+    "G2\tk__B; p__P1; c__C2; s__X y\textra column\n"
+    "G3\tk__B;p__P2\n"
+    "G4\tk__Arch; p__P3\n"
+    "G5\tk__B; p__P1; c__C1; s__Z\n")
+# Tree::parse_lineages by hand (src/phytree.cpp:320-369): taxa keep their first parent, children in attachment
+# order, post-order edge numbers, no branch lengths, a node "root" on top
+LINEAGES_SMALL_NWK = "((((G1{0},(G5{1})Z{2})C1{3},((G2{4})X y{5})C2{6})P1{7},(G3{8})P2{9})B{10},((G4{11})P3{12})Arch{13})root{14};"
+
+
+def test_oracle_lineage_tree(po, toy_index_dir, toy_reads):
+    ox = po.Index(toy_index_dir)
+    ox.set_lineage_tree(LINEAGES_SMALL)
+    assert ox.place_frame(1, False, "i", 0).split('"tree" : "')[1].split('"')[0] == LINEAGES_SMALL_NWK
+    for bad in ("G1\n", "G1\t\n", "\n", "G1\tk__A\nG1\tk__A\n"):
+        with pytest.raises(RuntimeError):
+            ox.set_lineage_tree(bad)
+    # the reference's toy lineages: 18 of the 25 references, one kingdom
+    lin = open(os.path.join(GOLDEN, "lineages_toy.txt")).read()
+    ox.set_lineage_tree(lin)
+    tree = ox.place_frame(1, False, "i", 0).split('"tree" : "')[1].split('"')[0]
+    assert tree.endswith(")Bacteria{%d})root{%d};" % (tree.count("{") - 2, tree.count("{") - 1))
+    assert tree.count("G0") == 18 and "k__" not in tree and "Chloroflexus aurantiacus" in tree
+    names, bases, offs = toy_reads
+    r = ox.place(bases, offs, names, po.params(no_filter=0))
+    pl = r["placements"]
+    assert len(pl) > 100
+    for rd in np.unique(pl["read"]):
+        assert abs(pl[pl["read"] == rd]["lwr"].sum() - 1.0) < 1e-9
+    assert (pl["distal"] == 0).all()  # no branch lengths in a taxonomy
+    # --summarize: every placed read counts once
+    txt = ox.place_summarize(bases, offs, po.params(no_filter=0))
+    rows = [l.split("\t") for l in txt.splitlines()]
+    assert abs(sum(float(x[2]) for x in rows) - len(np.unique(pl["read"]))) < 1e-3
+    assert abs(sum(float(x[3]) for x in rows) - 1.0) < 1e-3
+    assert ox.place_frame(0, 2, "inv").endswith("DISTAL_NODE\tEDGE_NUM\tWEIGHTED_COUNT\tSEQUENCE_ABUNDANCE\n")
+
+
+def test_host_lineage_tree_matches_oracle(capi, po, toy_index_dir):
+    """kr_place_tree_create_lineage / kr_place_frame are host-only: no GPU needed."""
+    import ctypes as C
+    lib = capi.load()
+    hx = capi.HostIndex(toy_index_dir)
+    ox = po.Index(toy_index_dir)
+    for lin in (LINEAGES_SMALL, open(os.path.join(GOLDEN, "lineages_toy.txt")).read()):
+        ox.set_lineage_tree(lin)
+        pt = C.c_void_p()
+        capi.check(lib.kr_place_tree_create_lineage(hx.h, lin.encode(), C.byref(pt)))
+        for which, mode in ((0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2)):
+            txt, ln = C.c_void_p(), C.c_uint64()
+            capi.check(lib.kr_place_frame(pt, which, mode, b"inv", 7, C.byref(txt), C.byref(ln)))
+            assert C.string_at(txt, ln.value).decode() == ox.place_frame(which, mode, "inv", 7), (which, mode)
+            lib.kr_free(txt)
+        lib.kr_place_tree_free(pt)
+    pt = C.c_void_p()
+    for bad in (b"G1\n", b"G1\t\n", b"", b"G1\tk__A\nG1\tk__A\n"):
+        assert lib.kr_place_tree_create_lineage(hx.h, bad, C.byref(pt)) != 0
+    assert "more than once" in lib.kr_last_error().decode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [dict(), dict(multi=0), dict(no_filter=1)])
+def test_place_on_lineages_matches_oracle(capi, po, toy_index_dir, toy_reads, opts):
+    names, bases, offs = toy_reads
+    lin = open(os.path.join(GOLDEN, "lineages_toy.txt")).read()
+    hx = capi.HostIndex(toy_index_dir)
+    ox = po.Index(toy_index_dir)
+    ox.set_lineage_tree(lin)
+    okw = dict(no_filter=0)
+    okw.update(opts)
+    pk = dict(opts)
+    pk.pop("no_filter", None)
+    for tabular in (0, 1, 2):
+        placer = capi.Placer(hx, None, 0, tabular=tabular, max_reads=len(names), max_bases=len(bases), lineage_text=lin, **pk)
+        if opts.get("no_filter"):
+            placer.popts.no_filter = 1
+        text, pl = placer.place(bases, offs, names)
+        if tabular == 2:
+            assert text == "" and placer.summary() == ox.place_summarize(bases, offs, po.params(**okw))
+            assert len(placer.summary().splitlines()) > 5
+        else:
+            want = ox.place(bases, offs, names, po.params(**okw), tabular=bool(tabular))
+            assert placements_key(pl) == placements_key(want["placements"]) and len(pl) > 100
+            assert text == want["text"], (opts, tabular)
+        placer.close()
+
+
+@pytest.mark.gpu
+def test_place_summarize_on_backbone_matches_oracle(capi, po, toy_index_dir, toy_reads):
+    names, bases, offs = toy_reads
+    hx = capi.HostIndex(toy_index_dir)
+    ox = po.Index(toy_index_dir)
+    ox.set_placement_tree(None)
+    placer = capi.Placer(hx, None, 0, tabular=2, max_reads=100, max_bases=len(bases))
+    for lo in range(0, len(names), 100):  # several submits: the sums carry over
+        hi = min(len(names), lo + 100)
+        placer.place(bases[int(offs[lo]):int(offs[hi])], offs[lo:hi + 1] - offs[lo], names[lo:hi])
+    # the oracle sums in 512-read batches, this run in 100-read submits: equal to the printed precision
+    got = [l.split("\t") for l in placer.summary().splitlines()]
+    want = [l.split("\t") for l in ox.place_summarize(bases, offs, po.params(no_filter=0)).splitlines()]
+    assert [g[:2] for g in got] == [w[:2] for w in want] and len(got) > 10
+    for g, w in zip(got, want):
+        assert abs(float(g[2]) - float(w[2])) < 2e-5 and abs(float(g[3]) - float(w[3])) < 2e-5
+
+
+@pytest.mark.gpu
+def test_cli_place_lineages_and_summarize(po, toy_index_dir, toy_reads, tmp_path):
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "krepp_amd", "lib", "krepp")
+    fq = os.path.join(GOLDEN, "toy_reads.fq")
+    lf = os.path.join(GOLDEN, "lineages_toy.txt")
+    names, bases, offs = toy_reads
+    ox = po.Index(toy_index_dir)
+    ox.set_lineage_tree(open(lf).read())
+    r = subprocess.run([exe, "place", "-i", toy_index_dir, "-q", fq, "-l", lf], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "taxonomic lineage" in r.stderr
+    want = ox.place(bases, offs, names, po.params(no_filter=0))
+    inv = f"{exe} place -i {toy_index_dir} -q {fq} -l {lf}"
+    assert r.stdout == ox.place_frame(0) + want["text"] + ox.place_frame(1, False, inv, len(names))
+    r = subprocess.run([exe, "place", "-i", toy_index_dir, "-q", fq, "-l", lf, "--summarize"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    inv += " --summarize"
+    assert r.stdout == ox.place_frame(0, 2, inv) + ox.place_summarize(bases, offs, po.params(no_filter=0))
+    # on the backbone, with the device buffers forced to overflow so that batches are split and retried
+    ox.set_placement_tree(None)
+    env = dict(os.environ, KR_DEBUG_CLI_RECORDS="150")
+    r = subprocess.run([exe, "place", "-i", toy_index_dir, "-q", fq, "--summarize"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    inv = f"{exe} place -i {toy_index_dir} -q {fq} --summarize"
+    assert r.stdout == ox.place_frame(0, 2, inv) + ox.place_summarize(bases, offs, po.params(no_filter=0))
