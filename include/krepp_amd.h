@@ -242,7 +242,10 @@ KR_API int kr_batch_timing(kr_stream*, kr_timing* out);
 /* ------------------------------------------------------------------------- */
 /* Host helpers mirroring the reference's reader and writer.                    */
 /* ------------------------------------------------------------------------- */
-/* QSeq (src/rqseq.cpp:146-203): gz/FASTA/FASTQ batches of >= 76,800 bases.       */
+/* QSeq (src/rqseq.cpp:146-203): gz/FASTA/FASTQ batches of >= 76,800 bases.  Plain (uncompressed)   */
+/* regular files of >= 32 MB are cut at record starts and parsed by a thread pool (KR_FASTX_THREADS,   */
+/* default min(8, cores/2); 0 = off): a batch is then one chunk of about 2 * min_bases bytes of input. */
+/* Records, names and order are those of the sequential reader in every case.                          */
 typedef struct kr_fastx kr_fastx;
 typedef struct kr_fastx_batch {
   const uint8_t* bases;
@@ -253,6 +256,7 @@ typedef struct kr_fastx_batch {
 } kr_fastx_batch;
 KR_API int kr_fastx_open(const char* path, kr_fastx** out);
 KR_API int kr_fastx_next(kr_fastx*, uint64_t min_bases, kr_fastx_batch* out);
+KR_API uint64_t kr_fastx_parallel_chunks(const kr_fastx*); /* chunks taken from the thread pool so far */
 KR_API void kr_fastx_close(kr_fastx*);
 
 /* report_distances text (src/query.cpp:158-196; DISTANCE_FIELDS src/query.hpp:210;

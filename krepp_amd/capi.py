@@ -90,7 +90,7 @@ EXPORTS = [
     "kr_debug_front_end", "kr_debug_brent", "kr_llh_batch", "kr_batch_timing",
     "kr_place_tree_create", "kr_place_tree_create_lineage", "kr_place_tree_nnodes", "kr_place_summary_add",
     "kr_place_summary_text", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_frame",
-    "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_format_dist", "kr_free",
+    "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_format_dist", "kr_free",
     "kr_build_index", "kr_minimizers_cpu", "kr_minimizers_device", "kr_minimizers_free", "kr_last_error", "kr_version",
 ]
 
@@ -437,9 +437,11 @@ class Stream:
             pass
 
 
-def read_fastx(path, min_bases=76800):
+def read_fastx(path, min_bases=76800, stats=None):
     """All records of a FASTA/FASTQ(.gz) file via the library's reader: (names, bases, offsets)."""
     lib = load()
+    lib.kr_fastx_parallel_chunks.restype = C.c_uint64
+    lib.kr_fastx_parallel_chunks.argtypes = [C.c_void_p]
     h = C.c_void_p()
     check(lib.kr_fastx_open(os.fsencode(str(path)), C.byref(h)))
     names, chunks, lens = [], [], []
@@ -455,6 +457,8 @@ def read_fastx(path, min_bases=76800):
             if not b.more:
                 break
     finally:
+        if stats is not None:
+            stats["parallel_chunks"] = int(lib.kr_fastx_parallel_chunks(h))
         lib.kr_fastx_close(h)
     bases = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
     offsets = np.zeros(len(lens) + 1, np.uint64)

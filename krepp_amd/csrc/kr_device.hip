@@ -1067,8 +1067,6 @@ __device__ __forceinline__ uint32_t alloc_records(const BatchOut& out, WaveState
 // holds -- in the wave's global scratch (L2): same code, memory operations by pointer type.
 __device__ __forceinline__ void mem_or(lds_u32* p, uint32_t v) { lds_or(p, v); }
 __device__ __forceinline__ void mem_or(uint32_t* p, uint32_t v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t mem_ld(lds_u32* p) { return *p; }
-__device__ __forceinline__ uint32_t mem_ld(uint32_t* p) { return gload(p); }
 __device__ __forceinline__ void mem_st(lds_u32* p, uint32_t v) { *p = v; }
 __device__ __forceinline__ void mem_st(uint32_t* p, uint32_t v) { gstore(p, v); }
 __device__ __forceinline__ void mem_sync(lds_u32*) { WAVE_SYNC(); }

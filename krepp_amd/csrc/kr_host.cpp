@@ -22,7 +22,14 @@
 #include <map>
 #include <memory>
 #include <set>
+#include <condition_variable>
+#include <deque>
+#include <fcntl.h>
+#include <mutex>
 #include <omp.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 #include <zlib.h>
 
 namespace kr {
@@ -545,8 +552,186 @@ void kr_params_default(kr_params* p)
 //    consumed; a short quality string ends reading like EOF (return -2 is < 0,
 //    src/rqseq.cpp:189).
 // ---------------------------------------------------------------------------
+namespace {
+// One four-line FASTQ record at b[p .. end) with a clean sequence line (graphic characters only, none of the
+// record markers) and a quality line of the same length -- the records for which kseq's character rules
+// reduce to "four lines".  `mk` is a marker kseq has already consumed (0: none).  Ok: name = b[nb .. ne),
+// sequence = b[s0 .. s0 + slen), the next record starts at `next`.  More: the record is not complete in the
+// buffer.  No: anything else (FASTA, wrapped lines, '\r', odd quality ...).
+enum class Clean { Ok, More, No };
+inline Clean clean_record(const unsigned char* b, size_t p, size_t end, int mk, size_t& nb, size_t& ne, size_t& s0, size_t& slen,
+                          size_t& next)
+{
+  if (mk == 0) {
+    if (p >= end) return Clean::More;
+    mk = b[p++];
+  }
+  if (mk != '@') return Clean::No;
+  const unsigned char* nl1 = p < end ? (const unsigned char*)memchr(b + p, '\n', end - p) : nullptr;
+  if (!nl1) return Clean::More;
+  s0 = (size_t)(nl1 - b) + 1;
+  const unsigned char* nl2 = s0 < end ? (const unsigned char*)memchr(b + s0, '\n', end - s0) : nullptr;
+  if (!nl2) return Clean::More;
+  slen = (size_t)(nl2 - b) - s0;
+  const size_t plus = s0 + slen + 1;
+  if (plus >= end) return Clean::More;
+  if (b[plus] != '+') return Clean::No;
+  const unsigned char* nl3 = (const unsigned char*)memchr(b + plus, '\n', end - plus);
+  if (!nl3) return Clean::More;
+  const size_t q0 = (size_t)(nl3 - b) + 1;
+  if (q0 + slen >= end) return Clean::More; // the quality characters and the one character kseq reads past them
+  unsigned bad = 0;
+  for (size_t i = 0; i < slen; ++i) {
+    const unsigned c = b[s0 + i];
+    bad |= (unsigned)(c - 33u > 93u) | (unsigned)(c == '>') | (unsigned)(c == '+') | (unsigned)(c == '@');
+  }
+  for (size_t i = 0; i < slen; ++i) bad |= (unsigned)((unsigned)b[q0 + i] - 33u > 94u);
+  if (bad) return Clean::No;
+  nb = p;
+  ne = p; // name: up to the first whitespace
+  while (ne < s0 - 1 && !isspace(b[ne])) ++ne;
+  next = q0 + slen + 1;
+  return Clean::Ok;
+}
+
+// ---- parallel parsing of plain (uncompressed) FASTQ files -------------------------------------------------
+// The file is cut into chunks at guessed record starts (a line starting with '@' whose second next line
+// starts with '+'); a pool of threads parses the chunks with clean_record.  A chunk counts only if its parse
+// starts at a verified record start (offset 0, or the exact end of the previous verified chunk) and consumes
+// the chunk exactly; by induction every accepted record is the one kseq would have produced.  The first chunk
+// that does not (other formats, a wrong guess, the tail of the file) hands its clean prefix over and the
+// reader continues sequentially -- character by character where needed -- from that offset.
+struct FqChunk {
+  uint64_t a = 0, b = 0; // file range
+  std::vector<uint8_t> bases;
+  std::vector<uint64_t> offsets{0};
+  std::string name_blob;
+  std::vector<size_t> name_off;
+  bool ok = false;       // consumed [a, b) exactly
+  uint64_t clean_end = 0; // file offset where the clean prefix ends
+  bool ready = false;
+};
+
+struct FqPool {
+  int fd = -1;
+  uint64_t size = 0, next_off = 0, chunk_bytes = 0;
+  bool issued_all = false;
+  size_t depth = 0;
+  std::deque<std::unique_ptr<FqChunk>> inflight; // file order
+  std::deque<FqChunk*> todo;
+  std::mutex mu;
+  std::condition_variable cv_todo, cv_ready;
+  bool stop = false;
+  std::vector<std::thread> threads;
+
+  static bool pread_all(int fd, unsigned char* dst, uint64_t off, size_t n)
+  {
+    while (n) {
+      ssize_t k = pread(fd, dst, n, (off_t)off);
+      if (k <= 0) return false;
+      dst += k, off += (uint64_t)k, n -= (size_t)k;
+    }
+    return true;
+  }
+  void parse(FqChunk& c)
+  {
+    std::vector<unsigned char> buf((size_t)(c.b - c.a));
+    size_t p = 0;
+    if (pread_all(fd, buf.data(), c.a, buf.size())) {
+      c.bases.reserve(buf.size() / 2);
+      size_t nb, ne, s0, slen, next;
+      while (p < buf.size() && clean_record(buf.data(), p, buf.size(), 0, nb, ne, s0, slen, next) == Clean::Ok) {
+        c.name_off.push_back(c.name_blob.size());
+        c.name_blob.append((const char*)buf.data() + nb, ne - nb);
+        c.name_blob.push_back('\0');
+        c.bases.insert(c.bases.end(), buf.data() + s0, buf.data() + s0 + slen);
+        c.offsets.push_back(c.bases.size());
+        p = next;
+      }
+    }
+    c.ok = p == buf.size() && !buf.empty();
+    c.clean_end = c.a + p;
+  }
+  void work()
+  {
+    for (;;) {
+      FqChunk* c = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_todo.wait(lk, [&] { return stop || !todo.empty(); });
+        if (stop) return;
+        c = todo.front();
+        todo.pop_front();
+      }
+      parse(*c);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        c->ready = true;
+      }
+      cv_ready.notify_all();
+    }
+  }
+  // a record start at or after t: UINT64_MAX if none is found nearby
+  uint64_t boundary(uint64_t t)
+  {
+    if (t >= size) return size;
+    std::vector<unsigned char> w((size_t)std::min<uint64_t>(256u << 10, size - t));
+    if (!pread_all(fd, w.data(), t, w.size())) return UINT64_MAX;
+    const unsigned char *b = w.data(), *e = b + w.size();
+    const unsigned char* nl = (const unsigned char*)memchr(b, '\n', w.size());
+    for (int tries = 0; nl && tries < 16; ++tries) {
+      const unsigned char* c = nl + 1;
+      if (c >= e) break;
+      const unsigned char* l1 = (const unsigned char*)memchr(c, '\n', (size_t)(e - c));
+      if (!l1) break;
+      const unsigned char* l2 = l1 + 1 < e ? (const unsigned char*)memchr(l1 + 1, '\n', (size_t)(e - l1 - 1)) : nullptr;
+      if (!l2 || l2 + 1 >= e) break;
+      if (*c == '@' && l2[1] == '+') return t + (uint64_t)(c - b);
+      nl = l1;
+    }
+    return UINT64_MAX;
+  }
+  void issue()
+  {
+    while (!issued_all && inflight.size() < depth) {
+      const uint64_t b = next_off >= size ? size : boundary(next_off + chunk_bytes);
+      if (next_off >= size || b == UINT64_MAX || b <= next_off) { // end of file, or no usable cut: the rest is sequential
+        issued_all = true;
+        break;
+      }
+      std::unique_ptr<FqChunk> c(new FqChunk());
+      c->a = next_off, c->b = b;
+      next_off = b;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        todo.push_back(c.get());
+      }
+      inflight.push_back(std::move(c));
+      cv_todo.notify_one();
+    }
+  }
+  void shutdown()
+  {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_todo.notify_all();
+    for (auto& t : threads) t.join();
+    threads.clear();
+    inflight.clear();
+    todo.clear();
+    if (fd >= 0) close(fd);
+    fd = -1;
+  }
+};
+} // namespace
+
 struct kr_fastx {
   gzFile f = nullptr;
+  std::string path;
+  std::unique_ptr<FqPool> pool; // plain files: chunks parsed in parallel while this is set
+  uint64_t pool_chunks = 0;     // chunks accepted from the pool
   std::vector<unsigned char> buf;
   size_t pos = 0, end = 0;
   bool eof = false;
@@ -600,45 +785,17 @@ struct kr_fastx {
   bool fast_fastq(std::string& name, std::vector<uint8_t>& seq_out, long& slen_out)
   {
     for (int attempt = 0; attempt < 2; ++attempt) {
-      const unsigned char* b = buf.data();
-      size_t p = pos;
-      int mk = last_char;
-      if (mk == 0) {
-        if (p >= end) goto more;
-        mk = b[p++];
-      }
-      if (mk != '@') return false;
-      {
-        const unsigned char* nl1 = p < end ? (const unsigned char*)memchr(b + p, '\n', end - p) : nullptr;
-        if (!nl1) goto more;
-        const size_t s0 = (size_t)(nl1 - b) + 1;
-        const unsigned char* nl2 = s0 < end ? (const unsigned char*)memchr(b + s0, '\n', end - s0) : nullptr;
-        if (!nl2) goto more;
-        const size_t slen = (size_t)(nl2 - b) - s0;
-        const size_t plus = s0 + slen + 1;
-        if (plus >= end) goto more;
-        if (b[plus] != '+') return false;
-        const unsigned char* nl3 = (const unsigned char*)memchr(b + plus, '\n', end - plus);
-        if (!nl3) goto more;
-        const size_t q0 = (size_t)(nl3 - b) + 1;
-        if (q0 + slen >= end) goto more; // the quality characters and the one character kseq reads past them
-        unsigned bad = 0;
-        for (size_t i = 0; i < slen; ++i) {
-          const unsigned c = b[s0 + i];
-          bad |= (unsigned)(c - 33u > 93u) | (unsigned)(c == '>') | (unsigned)(c == '+') | (unsigned)(c == '@');
-        }
-        for (size_t i = 0; i < slen; ++i) bad |= (unsigned)((unsigned)b[q0 + i] - 33u > 94u);
-        if (bad) return false;
-        size_t ne = p; // name: up to the first whitespace
-        while (ne < s0 - 1 && !isspace(b[ne])) ++ne;
-        name.assign((const char*)b + p, ne - p);
-        seq_out.insert(seq_out.end(), b + s0, b + s0 + slen);
-        pos = q0 + slen + 1;
+      size_t nb, ne, s0, slen, next;
+      const Clean c = clean_record(buf.data(), pos, end, last_char, nb, ne, s0, slen, next);
+      if (c == Clean::No) return false;
+      if (c == Clean::Ok) {
+        name.assign((const char*)buf.data() + nb, ne - nb);
+        seq_out.insert(seq_out.end(), buf.data() + s0, buf.data() + s0 + slen);
+        pos = next;
         last_char = 0;
         slen_out = (long)slen;
         return true;
       }
-    more:
       if (attempt == 1 || eof || (pos == 0 && end == buf.size())) return false;
       fill_keep();
     }
@@ -705,7 +862,28 @@ int kr_fastx_open(const char* path, kr_fastx** out)
   gzbuffer(f, 1 << 20);
   kr_fastx* r = new kr_fastx();
   r->f = f;
+  r->path = path;
   r->buf.resize(4 << 20);
+  // plain regular files of some size: parse in parallel (KR_FASTX_THREADS=0 turns it off; KR_FASTX_PAR_MIN = bytes)
+  {
+    const char* et = getenv("KR_FASTX_THREADS");
+    const char* em = getenv("KR_FASTX_PAR_MIN");
+    unsigned nt = et ? (unsigned)atoi(et) : std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    const uint64_t par_min = em ? strtoull(em, nullptr, 10) : (32ull << 20);
+    struct stat sb;
+    const bool regular = nt && stat(path, &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size >= par_min; // never a pipe
+    int fd = regular ? open(path, O_RDONLY) : -1;
+    unsigned char magic[2] = {0, 0};
+    if (fd >= 0 && pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+      r->pool.reset(new FqPool());
+      r->pool->fd = fd;
+      r->pool->size = (uint64_t)sb.st_size;
+      r->pool->depth = 2 * nt;
+      for (unsigned t = 0; t < nt; ++t) r->pool->threads.emplace_back([p = r->pool.get()] { p->work(); });
+    } else if (fd >= 0) {
+      close(fd);
+    }
+  }
   *out = r;
   return KR_OK;
 }
@@ -719,10 +897,39 @@ int kr_fastx_next(kr_fastx* r, uint64_t min_bases, kr_fastx_batch* out)
   r->offsets.assign(1, 0);
   r->name_blob.clear();
   r->name_off.clear();
+  uint64_t bpc = 0;
+  if (r->pool) { // one chunk of about 2 * min_bases bytes of input per batch (about min_bases bases of ordinary FASTQ)
+    FqPool& P = *r->pool;
+    if (!P.chunk_bytes) P.chunk_bytes = std::max<uint64_t>(4096, 2 * min_bases);
+    P.issue();
+    uint64_t resume = P.next_off; // where sequential parsing takes over if no chunk is left
+    bool fall_back = P.inflight.empty();
+    if (!fall_back) {
+      std::unique_ptr<FqChunk> c = std::move(P.inflight.front());
+      P.inflight.pop_front();
+      {
+        std::unique_lock<std::mutex> lk(P.mu);
+        P.cv_ready.wait(lk, [&] { return c->ready; });
+      }
+      r->bases.swap(c->bases);
+      r->offsets.swap(c->offsets);
+      r->name_blob.swap(c->name_blob);
+      r->name_off.swap(c->name_off);
+      bpc = r->bases.size();
+      if (!c->ok) fall_back = true, resume = c->clean_end;
+      else P.issue(), r->pool_chunks++;
+    }
+    if (fall_back) { // the rest of the input goes through the sequential reader
+      P.shutdown();
+      r->pool.reset();
+      if (gzseek(r->f, (z_off_t)resume, SEEK_SET) < 0) return kr::fail(KR_ERR_IO, "kr_fastx_next: seek failed in " + r->path);
+      r->pos = r->end = 0, r->eof = false, r->last_char = 0;
+    }
+    if (!r->name_off.empty()) bpc = std::max<uint64_t>(bpc, min_bases); // a batch is ready: hand it over as it is
+  }
   std::string name;
   bool cont = false;
-  uint64_t bpc = 0;
-  while (!r->done && bpc < min_bases) {
+  while (!r->pool && !r->done && bpc < min_bases) {
     long l = r->next_record(name, r->bases);
     cont = l >= 0;
     if (!cont) {
@@ -745,9 +952,12 @@ int kr_fastx_next(kr_fastx* r, uint64_t min_bases, kr_fastx_batch* out)
   return KR_OK;
 }
 
+uint64_t kr_fastx_parallel_chunks(const kr_fastx* r) { return r ? r->pool_chunks : 0; }
+
 void kr_fastx_close(kr_fastx* r)
 {
   if (!r) return;
+  if (r->pool) r->pool->shutdown();
   if (r->f) gzclose(r->f);
   delete r;
 }

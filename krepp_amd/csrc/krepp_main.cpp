@@ -17,6 +17,7 @@
 #include <cstring>
 #include <ctime>
 #include <deque>
+#include <atomic>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -183,6 +184,13 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
   bool eof = false;
   uint64_t total_batches = 0;
   std::string worker_err;
+  // KR_CLI_TIMING=1: seconds spent parsing, on the device (submit + collect), formatting and writing
+  const bool timing = getenv("KR_CLI_TIMING") != nullptr;
+  std::atomic<uint64_t> ns_parse{0}, ns_job{0}, ns_dev{0}, ns_fmt{0}, ns_write{0};
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto since = [](std::chrono::steady_clock::time_point t) {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count();
+  };
   std::map<uint32_t, double> wcount; // --summarize: reference -> weighted read count (src/krepp.cpp:374-378)
   double twcount = 0;
 
@@ -218,9 +226,12 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
         kr_result_view rv;
         char* txt = nullptr;
         uint64_t len = 0;
+        auto t_dev = now();
         int rc = kr_batch_submit(st, j->bases.data() + j->offsets[lo], offs.data(), (uint32_t)(hi - lo),
                                  KR_BASES_HOST | (place ? KR_TAP_ACCS : 0u));
         if (!rc) rc = kr_batch_collect(st, &rv);
+        ns_dev += since(t_dev);
+        auto t_fmt = now();
         if (rc == KR_ERR_CAPACITY && hi - lo > 1) {
           const size_t mid = lo + (hi - lo) / 2;
           rc = run(lo, mid);
@@ -250,6 +261,7 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
         }
         if (!rc && txt) text.append(txt, len);
         kr_free(txt);
+        ns_fmt += since(t_fmt);
         return rc;
       };
       const int rc = run(0, j->names.size());
@@ -307,7 +319,9 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
           jplace_prev = true;
         }
       } else {
+        auto t_w = now();
         fwrite(j->text.data(), 1, j->text.size(), out);
+        ns_write += since(t_w);
       }
       delete j;
       ++next;
@@ -320,7 +334,10 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
   uint64_t nbatches = 0, nreads_total = 0;
   for (;;) {
     kr_fastx_batch b;
+    auto t_parse = now();
     if (kr_fastx_next(fx, batch_bases, &b)) error_exit(kr_last_error());
+    ns_parse += since(t_parse);
+    auto t_job = now();
     // split over-long batches so that they fit the stream limits
     uint32_t r0 = 0;
     while (r0 < b.nreads) {
@@ -344,6 +361,7 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
       cv_work.notify_all();
       r0 = r1;
     }
+    ns_job += since(t_job);
     if (!b.more) break;
   }
   kr_fastx_close(fx);
@@ -383,6 +401,9 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
   double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   fprintf(stderr, place ? "Done placing queries, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n" : "Done estimating distances, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n", sec,
           sec > 0 ? nreads_total / sec : 0.0, ngpus);
+  if (timing)
+    fprintf(stderr, "[timing] parse %.3f s, job hand-over (incl. waiting for queue space) %.3f s, device %.3f s, format %.3f s, write %.3f s\n",
+            ns_parse / 1e9, ns_job / 1e9, ns_dev / 1e9, ns_fmt / 1e9, ns_write / 1e9);
   fprintf(stderr, "Total number of sequences queried: %llu\n", (unsigned long long)nreads_total);
   return 0;
 }

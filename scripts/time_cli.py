@@ -26,6 +26,7 @@ with open(fq, "wb") as f:
 exe = os.path.join(root, "krepp_amd", "lib", "krepp")
 for extra in ([], [], ["--summarize"]):
     t = time.time()
-    r = subprocess.run([exe, "dist", "-i", idx, "-q", fq, "-o", os.path.join(work, "out.tsv")] + extra, capture_output=True, text=True)
+    r = subprocess.run([exe, "dist", "-i", idx, "-q", fq, "-o", os.path.join(work, "out.tsv")] + extra, capture_output=True, text=True, env=dict(os.environ, KR_CLI_TIMING="1"))
+    print(r.stderr.strip().splitlines()[-3:])
     dt = time.time() - t
     print(" ".join(extra) or "rows", "rc", r.returncode, "reads", n, "seconds %.2f" % dt, "reads/s %.3g" % (n / dt), "output MB %.1f" % (os.path.getsize(os.path.join(work, "out.tsv")) / 1e6))

@@ -121,6 +121,69 @@ def test_fastx_reader_matches_reference_kseq(capi, tmp_path):
         assert ref.ref_kseq_parse(str(p).encode(), nb, 1024, sb, 1024, C.byref(last)) == 1 and last.value == -2
 
 
+def _read_both_ways(capi, path, min_bases):
+    """the same file through the sequential reader and through the parallel chunk parser"""
+    out = []
+    for threads in ("0", "3"):
+        os.environ["KR_FASTX_THREADS"], os.environ["KR_FASTX_PAR_MIN"] = threads, "0"
+        try:
+            st = {}
+            n, b, o = capi.read_fastx(str(path), min_bases=min_bases, stats=st)
+        finally:
+            del os.environ["KR_FASTX_THREADS"], os.environ["KR_FASTX_PAR_MIN"]
+        out.append((n, [bytes(b[int(o[i]):int(o[i + 1])]) for i in range(len(n))], st["parallel_chunks"]))
+    return out
+
+
+def test_parallel_fastq_reader_equals_sequential(capi, tmp_path):
+    """Plain files are cut into chunks at guessed record starts and parsed by a thread pool; whatever the
+    input, the records must be those of the sequential kseq-rule reader (which the golden vectors pin)."""
+    rng = np.random.default_rng(5)
+    qual_alphabet = np.frombuffer(bytes(range(33, 127)), np.uint8)
+
+    def record(i, n=None):
+        n = int(rng.integers(1, 200)) if n is None else n
+        seq = rng.choice(np.frombuffer(b"ACGTN", np.uint8), n).tobytes()
+        qual = rng.choice(qual_alphabet, n).tobytes()
+        if i % 7 == 0:
+            qual = b"@" + qual[1:]  # a quality line that looks like a header
+        if i % 11 == 0:
+            qual = b"+" + qual[1:]
+        return b"@r%d some comment\n" % i + seq + b"\n+\n" + qual + b"\n"
+
+    clean = [record(i) for i in range(4000)]
+    ks = json.load(open(os.path.join(GOLDEN, "kseq_ref.json")))
+    cases = {
+        "clean": b"".join(clean),
+        "no_final_newline": b"".join(clean)[:-1],
+        "wrapped_in_the_middle": b"".join(clean[:1500]) + b"@w x\nACGT\nACGT\n+\nIIII\nIIII\n" + b"".join(clean[1500:]),
+        "fasta_tail": b"".join(clean[:2500]) + b">f1\nACGTACGT\nACGT\n>f2\nAC\n",
+        "crlf": b"".join(clean[:800]) + b"".join(clean[800:900]).replace(b"\n", b"\r\n") + b"".join(clean[900:1200]),
+        "leading_junk": b"junk\n" + b"".join(clean[:300]),
+        "edge_vectors_after_clean": b"".join(clean[:2000]) + ks["edge_text"].encode(),
+        "truncated_after_clean": b"".join(clean[:2000]) + ks["trunc_text"].encode(),
+        "fasta_only": b"".join(b">s%d\n" % i + rng.choice(np.frombuffer(b"ACGT", np.uint8), 300).tobytes() + b"\n" for i in range(300)),
+        "empty": b"",
+    }
+    for key, data in cases.items():
+        p = tmp_path / (key + ".fq")
+        p.write_bytes(data)
+        for mb in (1, 5000):  # 4 KB and 10 KB chunks: hundreds of chunk boundaries per file
+            seq_res, par_res = _read_both_ways(capi, p, mb)
+            assert par_res[0] == seq_res[0], (key, mb)
+            assert par_res[1] == seq_res[1], (key, mb)
+            assert seq_res[2] == 0
+            if key in ("clean", "no_final_newline", "wrapped_in_the_middle", "fasta_tail", "crlf"):
+                assert par_res[2] > 10, (key, mb, par_res[2])  # the pool did parse most of the file
+            if key in ("leading_junk", "fasta_only", "empty"):
+                assert par_res[2] == 0
+        if key == "clean":
+            assert seq_res[0] == ["r%d" % i for i in range(4000)]
+            assert seq_res[1] == [r.split(b"\n")[1] for r in clean]
+        if key == "edge_vectors_after_clean":
+            assert seq_res[0][2000:] == ks["edge"]["names"]
+
+
 def test_builder_output_is_consistent_with_brute_force(capi, po, synth, tmp_path):
     """Independent check of the CPU builder: recompute, in pure Python, the minimizers of tiny
     genomes (src/rqseq.cpp:51-144 semantics) and the genome set of every indexed k-mer, and
