@@ -57,7 +57,7 @@ static Args parse(int argc, char** argv)
   for (int i = 1; i < argc; ++i) {
     std::string t = argv[i];
     if (t == "--help") {
-      printf("krepp (MI355X build): sub-commands `dist` and `index`; see INTEGRATION.md\n");
+      printf("krepp (MI355X build): sub-commands `dist`, `place` and `index`; see INTEGRATION.md\n");
       exit(0);
     }
     if (t[0] != '-') {
@@ -175,7 +175,7 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
   kr_params_default(&pfront);
   pfront.hdist_th = p.hdist_th;
 
-  const uint32_t max_reads = 1u << 16;
+  const uint32_t max_reads = getenv("KR_CLI_BATCH_READS") ? (uint32_t)std::max(1, atoi(getenv("KR_CLI_BATCH_READS"))) : (1u << 16);
   const uint64_t batch_bases = (uint64_t)max_reads * 150, max_bases = batch_bases * 4;
   std::mutex mu;
   std::condition_variable cv_work, cv_done;
@@ -278,8 +278,11 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
     }
     kr_stream_destroy(st);
   };
+  // two workers (each with its own stream) per GPU: one formats its rows while the other's batch is on the device
+  const int wpg = getenv("KR_CLI_WORKERS_PER_GPU") ? std::max(1, atoi(getenv("KR_CLI_WORKERS_PER_GPU"))) : 2;
+  const int nworkers = ngpus * wpg;
   std::vector<std::thread> workers;
-  for (int g = 0; g < ngpus; ++g) workers.emplace_back(worker, g);
+  for (int w = 0; w < nworkers; ++w) workers.emplace_back(worker, w % ngpus);
 
   bool jplace_prev = false;
   // place --summarize: counts per placement-tree node, summed by the writer in input order; placements of a
@@ -355,7 +358,7 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
         std::unique_lock<std::mutex> lk(mu);
         j->seq = nbatches++;
         // bound the number of batches in flight
-        cv_work.wait(lk, [&] { return todo.size() < (size_t)(2 * ngpus) || !worker_err.empty(); });
+        cv_work.wait(lk, [&] { return todo.size() < (size_t)(2 * nworkers) || !worker_err.empty(); });
         todo.push_back(j);
       }
       cv_work.notify_all();

@@ -24,9 +24,11 @@ with open(fq, "wb") as f:
         f.write(b"".join(rows))
         done += m
 exe = os.path.join(root, "krepp_amd", "lib", "krepp")
-for extra in ([], [], ["--summarize"]):
+for extra, env in (([], {}), ([], {"KR_CLI_BATCH_READS": "262144"}), ([], {"KR_CLI_BATCH_READS": "262144", "KR_CLI_WORKERS_PER_GPU": "1"}),
+                   ([], {"KR_FASTX_THREADS": "0", "KR_CLI_WORKERS_PER_GPU": "1"}), (["--summarize"], {})):
     t = time.time()
-    r = subprocess.run([exe, "dist", "-i", idx, "-q", fq, "-o", os.path.join(work, "out.tsv")] + extra, capture_output=True, text=True, env=dict(os.environ, KR_CLI_TIMING="1"))
-    print(r.stderr.strip().splitlines()[-3:])
+    r = subprocess.run([exe, "dist", "-i", idx, "-q", fq, "-o", os.path.join(work, "out.tsv")] + extra, capture_output=True, text=True,
+                       env=dict(os.environ, KR_CLI_TIMING="1", **env))
+    print(env, [l for l in r.stderr.strip().splitlines() if "timing" in l or "elapsed" in l])
     dt = time.time() - t
     print(" ".join(extra) or "rows", "rc", r.returncode, "reads", n, "seconds %.2f" % dt, "reads/s %.3g" % (n / dt), "output MB %.1f" % (os.path.getsize(os.path.join(work, "out.tsv")) / 1e6))
