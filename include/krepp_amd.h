@@ -86,6 +86,9 @@ typedef struct kr_index_view {
 } kr_index_view;
 
 KR_API int kr_host_index_load(const char* index_dir, kr_host_index** out);
+/* `krepp seek` (src/sketch.cpp:3-39): a single-reference sketch file presented as an index with one library
+ * and a one-leaf tree, so that kr_index_upload / kr_stream_* / kr_batch_* serve it unchanged. */
+KR_API int kr_host_sketch_load(const char* sketch_path, kr_host_index** out);
 KR_API void kr_host_index_free(kr_host_index*);
 KR_API int kr_host_index_view(const kr_host_index*, kr_index_view* out);
 /* Node::get_name (src/phytree.hpp:134-145): label, or se-1 for unlabelled nodes. */
@@ -263,6 +266,10 @@ KR_API void kr_fastx_close(kr_fastx*);
  * std::fixed, precision 5 src/query.cpp:152-153).  Appends to a malloc'ed buffer. */
 KR_API int kr_format_dist(const kr_host_index*, const kr_result_view*, const char* const* names, char** text,
                           uint64_t* len);
+/* `krepp seek` rows `SEQ_ID\tDIST` / `SEQ_ID\tNaN` (SBatch::seek_sequences, src/seek.cpp:22-56) from a batch
+ * on a sketch index; stream parameters multi = 1, no_filter = 1, dist_max unset. */
+KR_API int kr_format_seek(const kr_host_index*, const kr_index*, const kr_result_view*, uint32_t hdist_th,
+                          const char* const* names, char** text, uint64_t* len);
 KR_API void kr_free(void*);
 
 /* ------------------------------------------------------------------------- */
@@ -320,6 +327,9 @@ typedef struct kr_build_params {
 } kr_build_params;
 KR_API int kr_build_index(const char* input_tsv, const char* nwk_path /*may be NULL*/, const char* out_dir,
                           const kr_build_params*);
+/* `krepp sketch` (SketchSingle::create_sketch / save_sketch, src/krepp.cpp:110-129): the minimizers of one
+ * FASTA/FASTQ file in the reference's sketch format (defaults there: k 26, w k+6, h k-16, m 4, r 1, frac). */
+KR_API int kr_build_sketch(const char* input_path, const char* out_path, const kr_build_params*);
 
 /* The leaf stage of the build on its own: RSeq::extract_mers (src/rqseq.cpp:51-144) + the
  * sort/unique of DynHT::fill_table (src/table.cpp:247-260) for ONE genome held in memory

@@ -82,7 +82,7 @@ class KrBuildParams(C.Structure):
 
 # every symbol include/krepp_amd.h declares (tests check that the library exports them all)
 EXPORTS = [
-    "kr_host_index_load", "kr_host_index_free", "kr_host_index_view", "kr_host_index_node_name",
+    "kr_host_index_load", "kr_host_sketch_load", "kr_format_seek", "kr_build_sketch", "kr_host_index_free", "kr_host_index_view", "kr_host_index_node_name",
     "kr_host_index_node_label", "kr_host_index_node_parent", "kr_host_index_node_blen",
     "kr_index_upload", "kr_index_free", "kr_index_export", "kr_index_import", "kr_index_device_bytes",
     "kr_params_default", "kr_stream_create", "kr_stream_destroy", "kr_batch_submit", "kr_batch_wait",
@@ -192,10 +192,15 @@ def _np(ptr, n, dtype):
 class HostIndex:
     """Index directory read into host memory (reference: TargetIndex::load_index, src/krepp.cpp:66-108)."""
 
-    def __init__(self, index_dir):
+    def __init__(self, index_dir, sketch=False):
+        """sketch=True: `index_dir` is a `krepp sketch` file (kr_host_sketch_load), served as a one-leaf index"""
         self.lib = load()
         self.h = C.c_void_p()
-        check(self.lib.kr_host_index_load(os.fsencode(str(index_dir)), C.byref(self.h)))
+        if sketch:
+            self.lib.kr_host_sketch_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+            check(self.lib.kr_host_sketch_load(os.fsencode(str(index_dir)), C.byref(self.h)))
+        else:
+            check(self.lib.kr_host_index_load(os.fsencode(str(index_dir)), C.byref(self.h)))
         self.view = KrIndexView()
         check(self.lib.kr_host_index_view(self.h, C.byref(self.view)))
 
@@ -416,6 +421,18 @@ class Stream:
         check(self.lib.kr_batch_timing(self.h, C.byref(t)))
         return t
 
+    def format_seek(self, host_index, device_index, names, hdist_th=4):
+        """`krepp seek` rows from the collected batch (kr_format_seek)"""
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        txt = C.c_void_p()
+        ln = C.c_uint64()
+        self.lib.kr_format_seek.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(KrResultView), C.c_uint32, C.POINTER(C.c_char_p),
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        check(self.lib.kr_format_seek(host_index.h, device_index.h, C.byref(self._rv), hdist_th, arr, C.byref(txt), C.byref(ln)))
+        s = C.string_at(txt, ln.value).decode()
+        self.lib.kr_free(txt)
+        return s
+
     def format_dist(self, host_index, names):
         arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
         txt = C.c_void_p()
@@ -478,6 +495,20 @@ def build_index(input_tsv, out_dir, nwk=None, k=29, w=35, h=13, m=4, r=1, frac=T
         p.ppos = C.cast(keep, u8p)
     check(lib.kr_build_index(os.fsencode(str(input_tsv)), os.fsencode(str(nwk)) if nwk else None,
                              os.fsencode(str(out_dir)), C.byref(p)))
+
+
+def build_sketch(input_path, out_path, k=26, w=None, h=None, m=4, r=1, frac=True, seed=0, ppos=None):
+    """`krepp sketch` (reference: src/krepp.cpp:110-129; defaults k 26, w k+6, h k-16)."""
+    lib = load()
+    w = k + 6 if w is None else w
+    h = k - 16 if h is None else h
+    p = KrBuildParams(k=k, w=w, h=h, m=m, r=r, frac=int(frac), num_threads=1, seed=seed, ppos=None, gpu_minimizers=0, device=0)
+    keep = None
+    if ppos is not None:
+        keep = (C.c_uint8 * len(ppos))(*ppos)
+        p.ppos = C.cast(keep, u8p)
+    lib.kr_build_sketch.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(KrBuildParams)]
+    check(lib.kr_build_sketch(os.fsencode(str(input_path)), os.fsencode(str(out_path)), C.byref(p)))
 
 
 def minimizers(bases, offsets, k, w, h, ppos, m=4, r=1, frac=True, device=None):

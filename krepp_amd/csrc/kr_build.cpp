@@ -284,6 +284,54 @@ uint64_t colour_of(const BuildTree& bt, Colours& col, uint32_t se, const uint32_
   return acc;
 }
 
+// the given positions, or LSHF::get_random_positions (src/lshf.cpp:126-147) with the thread-local mt19937 `gen`
+bool choose_positions(const kr_build_params* bp, const BuildCfg& c, LshPositions& lsh)
+{
+  lsh.k = c.k, lsh.h = c.h;
+  if (bp->ppos) {
+    lsh.ppos.assign(bp->ppos, bp->ppos + c.h);
+    std::sort(lsh.ppos.begin(), lsh.ppos.end(), std::greater<uint8_t>());
+  } else {
+    std::mt19937 gen;
+    if (bp->seed) gen.seed(bp->seed);
+    std::uniform_int_distribution<uint8_t> distrib(0, (uint8_t)(c.k - 1));
+    while (lsh.ppos.size() < c.h) {
+      uint8_t n = distrib(gen);
+      if (!std::count(lsh.ppos.begin(), lsh.ppos.end(), n)) lsh.ppos.push_back(n);
+    }
+    std::sort(lsh.ppos.begin(), lsh.ppos.end(), std::greater<uint8_t>());
+  }
+  lsh.pasc.assign(lsh.ppos.rbegin(), lsh.ppos.rend());
+  for (uint8_t p = 0; p < c.k; ++p)
+    if (!std::count(lsh.ppos.begin(), lsh.ppos.end(), p)) lsh.npos.push_back(p);
+  return lsh.pasc.size() == c.h && lsh.pasc.back() < c.k;
+}
+
+// BaseLSH::set_nrows (src/krepp.cpp:5-16)
+uint32_t nrows_of(const BuildCfg& c)
+{
+  uint32_t hash_size = 1u << (2 * c.h), full_res = hash_size % c.m, nrows;
+  if (c.frac) {
+    nrows = (hash_size / c.m) * (c.r + 1);
+    nrows = full_res > c.r ? nrows + (c.r + 1) : nrows + full_res;
+  } else {
+    nrows = hash_size / c.m;
+    nrows = full_res > c.r ? nrows + 1 : nrows;
+  }
+  return nrows;
+}
+
+// validate_configuration (src/krepp.hpp:59-90)
+const char* bad_configuration(const BuildCfg& c)
+{
+  if (c.w < c.k) return "The minimum minimizer window size (-w) is k (-k).";
+  if (c.h < 3 || c.h > 15) return "The number of LSH positions (-h) must be in [3,15].";
+  if (c.k > 31 || c.k < 19) return "The k-mer length (-k) must be in [19,31].";
+  if (c.k - c.h > 16) return "For compact k-mer encodings, h must be >= k-16.";
+  if (c.m == 0 || c.r >= c.m) return "need 0 <= r < m";
+  return nullptr;
+}
+
 bool write_file(const std::string& path, const void* hdr, size_t hdr_bytes, const void* data, size_t bytes)
 {
   FILE* f = fopen(path.c_str(), "wb");
@@ -300,12 +348,7 @@ extern "C" int kr_build_index(const char* input_tsv, const char* nwk_path, const
   kr::clear_error();
   if (!input_tsv || !out_dir || !bp) return kr::fail(KR_ERR_ARG, "kr_build_index: null argument");
   BuildCfg c{bp->k, bp->w, bp->h, bp->m, bp->r, bp->frac != 0};
-  // validate_configuration (src/krepp.hpp:59-90)
-  if (c.w < c.k) return kr::fail(KR_ERR_ARG, "The minimum minimizer window size (-w) is k (-k).");
-  if (c.h < 3 || c.h > 15) return kr::fail(KR_ERR_ARG, "The number of LSH positions (-h) must be in [3,15].");
-  if (c.k > 31 || c.k < 19) return kr::fail(KR_ERR_ARG, "The k-mer length (-k) must be in [19,31].");
-  if (c.k - c.h > 16) return kr::fail(KR_ERR_ARG, "For compact k-mer encodings, h must be >= k-16.");
-  if (c.m == 0 || c.r >= c.m) return kr::fail(KR_ERR_ARG, "need 0 <= r < m");
+  if (const char* why = bad_configuration(c)) return kr::fail(KR_ERR_ARG, why);
 
   // input map: name \t path (src/krepp.cpp:147-162)
   std::vector<Genome> genomes;
@@ -383,34 +426,8 @@ extern "C" int kr_build_index(const char* input_tsv, const char* nwk_path, const
 
   // LSH positions
   LshPositions lsh;
-  lsh.k = c.k, lsh.h = c.h;
-  if (bp->ppos) {
-    lsh.ppos.assign(bp->ppos, bp->ppos + c.h);
-    std::sort(lsh.ppos.begin(), lsh.ppos.end(), std::greater<uint8_t>());
-  } else { // LSHF::get_random_positions (src/lshf.cpp:126-147), thread-local mt19937 `gen`
-    std::mt19937 gen;
-    if (bp->seed) gen.seed(bp->seed);
-    std::uniform_int_distribution<uint8_t> distrib(0, (uint8_t)(c.k - 1));
-    while (lsh.ppos.size() < c.h) {
-      uint8_t n = distrib(gen);
-      if (!std::count(lsh.ppos.begin(), lsh.ppos.end(), n)) lsh.ppos.push_back(n);
-    }
-    std::sort(lsh.ppos.begin(), lsh.ppos.end(), std::greater<uint8_t>());
-  }
-  lsh.pasc.assign(lsh.ppos.rbegin(), lsh.ppos.rend());
-  for (uint8_t p = 0; p < c.k; ++p)
-    if (!std::count(lsh.ppos.begin(), lsh.ppos.end(), p)) lsh.npos.push_back(p);
-  if (lsh.pasc.size() != c.h || lsh.pasc.back() >= c.k) return kr::fail(KR_ERR_ARG, "bad LSH positions");
-
-  // set_nrows (src/krepp.cpp:5-16)
-  uint32_t hash_size = 1u << (2 * c.h), full_res = hash_size % c.m, nrows;
-  if (c.frac) {
-    nrows = (hash_size / c.m) * (c.r + 1);
-    nrows = full_res > c.r ? nrows + (c.r + 1) : nrows + full_res;
-  } else {
-    nrows = hash_size / c.m;
-    nrows = full_res > c.r ? nrows + 1 : nrows;
-  }
+  if (!choose_positions(bp, c, lsh)) return kr::fail(KR_ERR_ARG, "bad LSH positions");
+  const uint32_t nrows = nrows_of(c);
 
   // leaves: minimizers of every contig (DynHT::fill_table, src/table.cpp:247-260)
   int nthreads = bp->num_threads ? (int)bp->num_threads : 1;
@@ -634,4 +651,64 @@ extern "C" void kr_minimizers_free(kr_minimizer_result* r)
   free(r->keys);
   r->keys = nullptr;
   r->nkeys = 0;
+}
+
+// `krepp sketch` (SketchSingle::create_sketch / save_sketch, src/krepp.cpp:110-129): the minimizers of ONE
+// FASTA/FASTQ file as a table without colours.  SDynHT::fill_table (src/table.cpp:234-246) = extract_mers of
+// every record of length >= w, rows sorted by code, duplicates removed; file = SFlatHT::save
+// (src/table.cpp:34-40: nkmers u64, codes u32[], nrows u32, cumulative row ends u64[]) + save_configuration
+// (src/krepp.cpp:18-29) + rho f64.
+extern "C" int kr_build_sketch(const char* input_path, const char* out_path, const kr_build_params* bp)
+{
+  kr::clear_error();
+  if (!input_path || !out_path || !bp) return kr::fail(KR_ERR_ARG, "kr_build_sketch: null argument");
+  BuildCfg c{bp->k, bp->w, bp->h, bp->m, bp->r, bp->frac != 0};
+  if (const char* why = bad_configuration(c)) return kr::fail(KR_ERR_ARG, why);
+  LshPositions lsh;
+  if (!choose_positions(bp, c, lsh)) return kr::fail(KR_ERR_ARG, "bad LSH positions");
+  const uint32_t nrows = nrows_of(c);
+  kr_fastx* fx = nullptr;
+  if (kr_fastx_open(input_path, &fx) != KR_OK) return kr::fail(KR_ERR_IO, std::string("Failed to open the file at ") + input_path);
+  std::vector<uint64_t> keys;
+  double n1 = 0, n2 = 0;
+  kr_fastx_batch b;
+  do {
+    if (kr_fastx_next(fx, 1u << 20, &b)) {
+      kr_fastx_close(fx);
+      return KR_ERR_IO;
+    }
+    for (uint32_t q = 0; q < b.nreads; ++q) {
+      const uint64_t len = b.offsets[q + 1] - b.offsets[q];
+      if (len >= c.w) kr::extract_contig_cpu(b.bases + b.offsets[q], len, c, lsh, keys, n1, n2); // RSeq::set_curr_seq
+    }
+  } while (b.more);
+  kr_fastx_close(fx);
+  std::sort(keys.begin(), keys.end());
+  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  std::vector<uint32_t> enc(keys.size());
+  std::vector<uint64_t> inc(nrows, 0);
+  for (size_t i = 0; i < keys.size(); ++i) {
+    const uint32_t row = (uint32_t)(keys[i] >> 32);
+    if (row >= nrows) return kr::fail(KR_ERR_STATE, "kr_build_sketch: row out of range");
+    enc[i] = (uint32_t)keys[i];
+    inc[row]++;
+  }
+  for (uint32_t r = 1; r < nrows; ++r) inc[r] += inc[r - 1];
+  const double rho = n1 > 0 ? n2 / n1 : 0.0; // RSeq::compute_rho, src/rqseq.hpp:79
+  std::string blob;
+  const uint64_t nk = enc.size();
+  blob.append((const char*)&nk, 8);
+  blob.append((const char*)enc.data(), enc.size() * 4);
+  blob.append((const char*)&nrows, 4);
+  blob.append((const char*)inc.data(), inc.size() * 8);
+  const uint8_t k8 = (uint8_t)c.k, w8 = (uint8_t)c.w, h8 = (uint8_t)c.h, f8 = c.frac ? 1 : 0;
+  blob.append((const char*)&k8, 1), blob.append((const char*)&w8, 1), blob.append((const char*)&h8, 1);
+  blob.append((const char*)&c.m, 4), blob.append((const char*)&c.r, 4), blob.append((const char*)&f8, 1);
+  blob.append((const char*)&nrows, 4);
+  blob.append((const char*)lsh.ppos.data(), lsh.ppos.size());
+  blob.append((const char*)lsh.npos.data(), lsh.npos.size());
+  blob.append((const char*)&rho, 8);
+  if (!write_file(out_path, blob.data(), blob.size(), nullptr, 0)) return kr::fail(KR_ERR_IO, "Failed to write the sketch!");
+  fprintf(stderr, "Total number of k-mers included in the sketch: %llu\nSubsampling rate (rho) is: %g\n", (unsigned long long)nk, rho);
+  return KR_OK;
 }

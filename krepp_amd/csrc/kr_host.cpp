@@ -498,6 +498,77 @@ int kr_host_index_load(const char* index_dir, kr_host_index** out)
   return KR_OK;
 }
 
+// `krepp seek`: a sketch (Sketch::load_full_sketch, src/sketch.cpp:3-24; SFlatHT::load, src/table.cpp:24-33) is the
+// table of ONE reference without colours.  It is presented as an index with a single library and a one-leaf
+// tree -- every entry carries the colour of that leaf -- so that the device path of `dist` serves it unchanged:
+// per strand the accumulator of the only leaf IS SSummary's histogram (per k-mer position the minimum
+// Hamming distance over the bucket, src/seek.cpp:104-121).  rho is scaled as Sketch::make_rho_partial does
+// (src/sketch.cpp:26-33).
+int kr_host_sketch_load(const char* sketch_path, kr_host_index** out)
+{
+  kr::clear_error();
+  if (!sketch_path || !out) return kr::fail(KR_ERR_ARG, "kr_host_sketch_load: null argument");
+  *out = nullptr;
+  std::string buf;
+  if (!slurp(sketch_path, buf)) return kr::fail(KR_ERR_IO, std::string("Failed to read the sketch file! ") + sketch_path);
+  const std::string bad = "Failed to read the sketch file!";
+  size_t off = 0;
+  uint64_t nkmers = 0;
+  uint32_t nrows = 0, m = 0, r = 0, nrows2 = 0;
+  uint8_t k = 0, w = 0, h = 0, frac = 0;
+  if (!take(buf, off, nkmers) || nkmers > (buf.size() - off) / 4) return kr::fail(KR_ERR_FORMAT, bad);
+  const size_t enc_off = off;
+  off += (size_t)nkmers * 4;
+  if (!take(buf, off, nrows) || nrows > (buf.size() - off) / 8) return kr::fail(KR_ERR_FORMAT, bad);
+  const size_t inc_off = off;
+  off += (size_t)nrows * 8;
+  if (!take(buf, off, k) || !take(buf, off, w) || !take(buf, off, h) || !take(buf, off, m) || !take(buf, off, r) ||
+      !take(buf, off, frac) || !take(buf, off, nrows2))
+    return kr::fail(KR_ERR_FORMAT, bad);
+  if (k < 1 || k > 32 || h < 1 || h > k || m == 0 || off + k + 8 > buf.size()) return kr::fail(KR_ERR_FORMAT, bad);
+  std::unique_ptr<kr_host_index> hx(new kr_host_index());
+  hx->k = k, hx->h = h, hx->m = m;
+  hx->ppos.assign(buf.begin() + off, buf.begin() + off + h);
+  hx->npos.assign(buf.begin() + off + h, buf.begin() + off + k);
+  off += k;
+  double rho = 0;
+  take(buf, off, rho);
+  rho *= frac ? ((double)r + 1.0) / (double)m : 1.0 / (double)m;
+  kr_host_lib lib;
+  lib.r = r, lib.frac = frac, lib.w = w, lib.nrows_meta = nrows2;
+  lib.inc.resize(nrows);
+  memcpy(lib.inc.data(), buf.data() + inc_off, (size_t)nrows * 8);
+  if (nrows && lib.inc.back() != nkmers) return kr::fail(KR_ERR_FORMAT, bad);
+  lib.cmer.resize((size_t)nkmers * 2);
+  for (uint64_t i = 0; i < nkmers; ++i) {
+    memcpy(&lib.cmer[2 * i], buf.data() + enc_off + 4 * i, 4);
+    lib.cmer[2 * i + 1] = 1; // the colour of the only leaf
+  }
+  lib.nnodes = 2, lib.nsubsets = 2;
+  lib.pse.assign(4, 0);
+  lib.rho = {0.0, rho};
+  hx->libs.push_back(std::move(lib));
+  std::string label = sketch_path;
+  const size_t slash = label.rfind('/');
+  if (slash != std::string::npos) label = label.substr(slash + 1);
+  hx->tree.nodes.resize(2);
+  hx->tree.nodes[0] = kr::TreeNode{"", NAN, 0, 0};
+  hx->tree.nodes[1] = kr::TreeNode{label, NAN, 0, 1};
+  hx->names = {"", label};
+  hx->kind = {0, 1};
+  hx->wbackbone = false;
+  {
+    const kr_host_lib& L = hx->libs[0];
+    kr_lib_view v;
+    memset(&v, 0, sizeof(v));
+    v.inc = L.inc.data(), v.cmer = L.cmer.data(), v.pse = L.pse.data(), v.rho = L.rho.data();
+    v.nkmers = nkmers, v.nrows = nrows, v.nsubsets = L.nsubsets, v.nnodes = L.nnodes, v.r = r, v.frac = frac, v.w = w;
+    hx->lib_views.push_back(v);
+  }
+  *out = hx.release();
+  return KR_OK;
+}
+
 void kr_host_index_free(kr_host_index* h) { delete h; }
 
 int kr_host_index_view(const kr_host_index* h, kr_index_view* v)
@@ -1037,6 +1108,65 @@ int kr_format_dist(const kr_host_index* h, const kr_result_view* rv, const char*
   p[total] = 0;
   *text = p;
   *len = total;
+  return KR_OK;
+}
+
+// SBatch::seek_sequences (src/seek.cpp:22-56).  `rv` is a batch of the `dist` path on a sketch index
+// (kr_host_sketch_load), stream parameters multi = 1, no_filter = 1, no dist-max: one record per strand that
+// matched.  A read with any match reports the smaller of the two strands' distances -- `d_or < d_rc ? d_or :
+// d_rc` -- where a strand WITHOUT matches is still optimised, on an all-zero histogram with mismatch_count =
+// onmers: those minimisations (one per distinct onmers of the batch) run on the GPU through kr_llh_batch.
+int kr_format_seek(const kr_host_index* h, const kr_index* dix, const kr_result_view* rv, uint32_t hdist_th,
+                   const char* const* names, char** text, uint64_t* len)
+{
+  if (!h || !dix || !rv || !text || !len) return kr::fail(KR_ERR_ARG, "kr_format_seek: null argument");
+  if (h->libs.size() != 1 || h->libs[0].rho.size() != 2) return kr::fail(KR_ERR_ARG, "kr_format_seek: not a sketch index");
+  const double rho = h->libs[0].rho[1];
+  std::map<uint32_t, double> dzero; // onmers -> d of the empty strand
+  for (uint32_t r = 0; r < rv->nreads; ++r) {
+    const uint32_t o = rv->read_off[r], n = rv->read_cnt[r];
+    uint32_t nrec = 0;
+    for (uint32_t i = o; i < o + n; ++i) nrec += rv->rec_key[i] != 0;
+    if (nrec == 1) dzero[rv->read_onmers[r]] = 0;
+  }
+  if (!dzero.empty()) {
+    const size_t nz = dzero.size(), np = (size_t)hdist_th + 1;
+    std::vector<double> hist(nz * np, 0.0), uc(nz), rh(nz, rho), d(nz), v(nz);
+    size_t j = 0;
+    for (auto& kv : dzero) uc[j++] = (double)kv.first;
+    int rc = kr_llh_batch(dix, hdist_th, 0, nz, hist.data(), uc.data(), rh.data(), nullptr, d.data(), v.data());
+    if (rc) return rc;
+    j = 0;
+    for (auto& kv : dzero) kv.second = d[j++];
+  }
+  std::string s;
+  s.reserve((size_t)rv->nreads * 24);
+  char num[64];
+  for (uint32_t r = 0; r < rv->nreads; ++r) {
+    const char* id = names ? names[r] : "";
+    const uint32_t o = rv->read_off[r], n = rv->read_cnt[r];
+    bool have[2] = {false, false};
+    double ds[2] = {0, 0};
+    for (uint32_t i = o; i < o + n; ++i)
+      if (rv->rec_key[i]) have[rv->rec_key[i] & 1u] = true, ds[rv->rec_key[i] & 1u] = rv->rec_d[i];
+    s += id;
+    if (!have[0] && !have[1]) {
+      s += "\tNaN\n";
+      continue;
+    }
+    for (int q = 0; q < 2; ++q)
+      if (!have[q]) ds[q] = dzero[rv->read_onmers[r]];
+    const double dmin = ds[0] < ds[1] ? ds[0] : ds[1];
+    const size_t nl = fmt_fixed5(dmin, num);
+    s += '\t';
+    s.append(num, nl);
+    s += '\n';
+  }
+  char* p = (char*)malloc(s.size() + 1);
+  if (!p) return kr::fail(KR_ERR_NOMEM, "kr_format_seek: out of memory");
+  memcpy(p, s.c_str(), s.size() + 1);
+  *text = p;
+  *len = s.size();
   return KR_OK;
 }
 

@@ -57,7 +57,7 @@ static Args parse(int argc, char** argv)
   for (int i = 1; i < argc; ++i) {
     std::string t = argv[i];
     if (t == "--help") {
-      printf("krepp (MI355X build): sub-commands `dist`, `place` and `index`; see INTEGRATION.md\n");
+      printf("krepp (MI355X build): sub-commands `dist`, `place`, `seek`, `index`, `sketch`; see INTEGRATION.md\n");
       exit(0);
     }
     if (t[0] != '-') {
@@ -96,11 +96,14 @@ struct Job {
 };
 
 // `dist` and `place` share everything up to the per-batch back end (src/krepp.cpp:347-394, 434-504)
-static int run_query(const Args& a, const std::string& invocation, bool place)
+// mode 0 `dist`, 1 `place`, 2 `seek` (a sketch file served as a one-leaf index: src/krepp.cpp:321-345, src/seek.cpp)
+static int run_query(const Args& a, const std::string& invocation, int mode)
 {
-  if (!a.has("--query") || !a.has("--index-dir")) error_exit("dist/place require -q/--query and -i/--index-dir");
+  const bool place = mode == 1, seek = mode == 2;
+  const std::string index_arg = a.has("--index-dir") ? a.get("--index-dir") : a.get("--sketch-path");
+  if (!a.has("--query") || index_arg.empty()) error_exit("dist/place/seek require -q/--query and -i (index directory or sketch file)");
   if (a.has("--lineage-file") && !place) error_exit("-l/--lineage-file is an option of `place`");
-  const bool summarize = a.flag.count("--summarize") && a.flag.at("--summarize");
+  const bool summarize = !seek && a.flag.count("--summarize") && a.flag.at("--summarize");
   kr_params p;
   kr_params_default(&p);
   if (a.has("--hdist-th")) p.hdist_th = (uint32_t)atoi(a.get("--hdist-th").c_str());
@@ -129,7 +132,7 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
   }
   fprintf(stderr, "Loading the index and initializing...\n");
   kr_host_index* hx = nullptr;
-  if (kr_host_index_load(a.get("--index-dir").c_str(), &hx)) error_exit(kr_last_error());
+  if (seek ? kr_host_sketch_load(index_arg.c_str(), &hx) : kr_host_index_load(index_arg.c_str(), &hx)) error_exit(kr_last_error());
   kr_index_view view;
   kr_host_index_view(hx, &view);
   kr_place_tree* ptree = nullptr;
@@ -158,9 +161,12 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
   std::vector<kr_index*> dix(ngpus, nullptr);
   for (int g = 0; g < ngpus; ++g)
     if (kr_index_upload(&view, dev0 + g, KR_VIEW_HOST, &dix[g])) error_exit(kr_last_error());
-  if (!place) fprintf(stderr, "Estimating distances between given sequences and references...\n");
+  if (seek) fprintf(stderr, "Seeking query sequences in the sketch...\n");
+  if (!place && !seek) fprintf(stderr, "Estimating distances between given sequences and references...\n");
   auto t0 = std::chrono::steady_clock::now();
-  if (!place) { // header (src/krepp.cpp:311-319)
+  if (seek) { // QuerySketch::header_dreport (src/krepp.cpp:305-309)
+    fprintf(out, "# software: krepp\tversion: " KREPP_VERSION "\tinvocation :%s\nSEQ_ID\tDIST\n", invocation.c_str());
+  } else if (!place) { // header (src/krepp.cpp:311-319)
     fprintf(out, "# software: krepp\tversion: " KREPP_VERSION "\tinvocation :%s\n%s\n", invocation.c_str(),
             summarize ? "REFERENCE_NAME\tWEIGHTED_COUNT\tSEQUENCE_ABUNDANCE" : "SEQ_ID\tREFERENCE_NAME\tDIST");
   } else { // jplace opening or tabular header (src/krepp.cpp:440-447)
@@ -198,7 +204,7 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
     kr_stream* st = nullptr;
     uint64_t max_records = (uint64_t)max_reads * (place ? 128 : 64);
     if (const char* e = getenv("KR_DEBUG_CLI_RECORDS")) max_records = strtoull(e, nullptr, 10); // tests: force the split-and-retry path
-    if (kr_stream_create(dix[g], place ? &pfront : &p, max_reads, max_bases, max_records, &st)) {
+    if (kr_stream_create(dix[g], (place || seek) ? &pfront : &p, max_reads, max_bases, max_records, &st)) {
       std::lock_guard<std::mutex> lk(mu);
       worker_err = kr_last_error();
       cv_done.notify_all();
@@ -237,7 +243,8 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
           rc = run(lo, mid);
           return rc ? rc : run(mid, hi);
         }
-        if (!rc && !place && !summarize) rc = kr_format_dist(hx, &rv, nm.data() + lo, &txt, &len);
+        if (!rc && seek) rc = kr_format_seek(hx, dix[g], &rv, p.hdist_th, nm.data() + lo, &txt, &len);
+        if (!rc && !place && !seek && !summarize) rc = kr_format_dist(hx, &rv, nm.data() + lo, &txt, &len);
         if (!rc && summarize && !place) { // each read shares one unit among the references it keeps (src/query.cpp:168-170)
           std::lock_guard<std::mutex> lk(mu);
           for (uint32_t r = 0; r < rv.nreads; ++r) {
@@ -402,7 +409,7 @@ static int run_query(const Args& a, const std::string& invocation, bool place)
   for (auto* d : dix) kr_index_free(d);
   kr_host_index_free(hx);
   double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  fprintf(stderr, place ? "Done placing queries, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n" : "Done estimating distances, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n", sec,
+  fprintf(stderr, place ? "Done placing queries, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n" : seek ? "Done seeking query sequences, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n" : "Done estimating distances, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n", sec,
           sec > 0 ? nreads_total / sec : 0.0, ngpus);
   if (timing)
     fprintf(stderr, "[timing] parse %.3f s, job hand-over (incl. waiting for queue space) %.3f s, device %.3f s, format %.3f s, write %.3f s\n",
@@ -449,6 +456,30 @@ static int run_index(const Args& a)
   return 0;
 }
 
+static int run_sketch(const Args& a)
+{ // SketchSingle (src/krepp.cpp:516-541): -i,--input-file  -o,--output-path; defaults k 26, w k+6, h k-16, m 4, r 1, frac
+  const std::string input = a.has("--input-file") ? a.get("--input-file") : a.get("--index-dir");
+  const std::string outp = a.get("--output-path");
+  if (input.empty() || outp.empty()) error_exit("sketch requires -i/--input-file and -o/--output-path");
+  kr_build_params bp;
+  memset(&bp, 0, sizeof(bp));
+  bp.k = 26, bp.m = 4, bp.r = 1, bp.frac = 1;
+  if (a.has("--kmer-len")) bp.k = (uint32_t)atoi(a.get("--kmer-len").c_str());
+  bp.w = bp.k + 6, bp.h = bp.k - 16; // src/krepp.cpp:533-536 (and the defaults [k+6], [k-16])
+  if (a.has("--win-len")) {
+    bp.w = (uint32_t)atoi(a.get("--win-len").c_str());
+    bp.h = a.has("--num-positions") ? (uint32_t)atoi(a.get("--num-positions").c_str()) : 10; // h keeps its default
+  }
+  if (a.has("--modulo-lsh")) bp.m = (uint32_t)atoi(a.get("--modulo-lsh").c_str());
+  if (a.has("--residue-lsh")) bp.r = (uint32_t)atoi(a.get("--residue-lsh").c_str());
+  if (a.flag.count("--frac")) bp.frac = a.flag.at("--frac");
+  bp.seed = a.has("--seed") ? (uint32_t)atoi(a.get("--seed").c_str()) : 0;
+  fprintf(stderr, "Initializing the sketch...\n");
+  if (kr_build_sketch(input.c_str(), outp.c_str(), &bp)) error_exit(kr_last_error());
+  fprintf(stderr, "Done sketching & saving\n");
+  return 0;
+}
+
 int main(int argc, char** argv)
 {
   fprintf(stderr, "krepp version: " KREPP_VERSION " (krepp-amd, MI355X)\n"); // PRINT_VERSION, src/common.hpp:51
@@ -459,15 +490,19 @@ int main(int argc, char** argv)
   fprintf(stderr, "Invocation: %s\n%s", invocation.c_str(), std::ctime(&now));
   int rc;
   if (a.sub == "dist")
-    rc = run_query(a, invocation, false);
+    rc = run_query(a, invocation, 0);
   else if (a.sub == "place")
-    rc = run_query(a, invocation, true);
+    rc = run_query(a, invocation, 1);
+  else if (a.sub == "seek")
+    rc = run_query(a, invocation, 2);
   else if (a.sub == "index")
     rc = run_index(a);
-  else if (a.sub == "seek" || a.sub == "sketch" || a.sub == "inspect")
-    error_exit("sub-command `" + a.sub + "` is outside the scope of this build (dist/place/index only)");
+  else if (a.sub == "sketch")
+    rc = run_sketch(a);
+  else if (a.sub == "inspect")
+    error_exit("sub-command `inspect` is outside the scope of this build (dist/place/seek/index/sketch)");
   else
-    error_exit("A subcommand is required (dist | place | index)");
+    error_exit("A subcommand is required (dist | place | seek | index | sketch)");
   now = std::time(nullptr);
   fprintf(stderr, "%s", std::ctime(&now));
   return rc;

@@ -1852,4 +1852,168 @@ char* ko_place_frame(const ko_index* ix, int which, int tabular, const char* inv
   return r;
 }
 
+// ---------------------------------------------------------------------------
+// `krepp seek` (src/seek.cpp:1-126, src/sketch.cpp:3-39, src/sketch.hpp:18-22): a single-reference sketch.
+// ---------------------------------------------------------------------------
+struct ko_sketch {
+  uint64_t nkmers = 0;
+  uint32_t nrows = 0, m = 0, r = 0, nrows_cfg = 0;
+  uint8_t k = 0, w = 0, h = 0;
+  bool frac = false;
+  double rho = 0;
+  std::vector<uint32_t> enc_v; // SFlatHT (src/table.cpp:24-33)
+  std::vector<uint64_t> inc_v;
+  Lsh lsh;
+};
+
+ko_sketch* ko_sketch_load(const char* path, char* err, int errlen)
+{ // Sketch::load_full_sketch (src/sketch.cpp:3-24) + make_rho_partial (:26-33)
+  std::ifstream f(path, std::ifstream::binary);
+  std::unique_ptr<ko_sketch> sk(new ko_sketch());
+  bool ok = f.good() && rd(f, sk->nkmers);
+  if (ok) {
+    sk->enc_v.resize(sk->nkmers);
+    f.read((char*)sk->enc_v.data(), (std::streamsize)(sk->nkmers * 4));
+    ok = f.good() && rd(f, sk->nrows);
+  }
+  if (ok) {
+    sk->inc_v.resize(sk->nrows);
+    f.read((char*)sk->inc_v.data(), (std::streamsize)(sk->nrows * 8ull));
+    ok = f.good() && rd(f, sk->k) && rd(f, sk->w) && rd(f, sk->h) && rd(f, sk->m) && rd(f, sk->r) && rd(f, sk->frac) &&
+         rd(f, sk->nrows_cfg);
+  }
+  if (ok && sk->h <= sk->k) {
+    sk->lsh.ppos.resize(sk->h);
+    sk->lsh.npos.resize(sk->k - sk->h);
+    f.read((char*)sk->lsh.ppos.data(), sk->h);
+    f.read((char*)sk->lsh.npos.data(), sk->k - sk->h);
+    ok = f.good() && rd(f, sk->rho);
+  } else
+    ok = false;
+  if (!ok) {
+    set_err(err, errlen, "Failed to read the sketch file!");
+    return nullptr;
+  }
+  sk->lsh.m = sk->m;
+  sk->lsh.set();
+  if (sk->frac)
+    sk->rho *= ((double)sk->r + 1.0) / (double)sk->m;
+  else
+    sk->rho *= 1.0 / (double)sk->m;
+  return sk.release();
+}
+void ko_sketch_free(ko_sketch* sk) { delete sk; }
+void ko_sketch_info(const ko_sketch* sk, uint64_t* nkmers, uint32_t* nrows, uint32_t* k, uint32_t* w, uint32_t* h, uint32_t* m,
+                    uint32_t* r, uint32_t* frac, double* rho)
+{
+  *nkmers = sk->nkmers, *nrows = sk->nrows, *k = sk->k, *w = sk->w, *h = sk->h, *m = sk->m, *r = sk->r, *frac = sk->frac;
+  *rho = sk->rho;
+}
+const uint32_t* ko_sketch_codes(const ko_sketch* sk) { return sk->enc_v.data(); }
+const uint64_t* ko_sketch_inc(const ko_sketch* sk) { return sk->inc_v.data(); }
+void ko_sketch_positions(const ko_sketch* sk, uint8_t* ppos, uint8_t* npos)
+{
+  memcpy(ppos, sk->lsh.ppos.data(), sk->lsh.ppos.size());
+  memcpy(npos, sk->lsh.npos.data(), sk->lsh.npos.size());
+}
+
+// SBatch::seek_sequences (src/seek.cpp:22-56) over all reads; out->text = `SEQ_ID\tDIST` / `SEQ_ID\tNaN` rows,
+// out->rows: one row per read (se = 1 if a distance was reported, else 0).
+int ko_seek_batch(const ko_sketch* sk, const char* bases, const uint64_t* offsets, const char* const* names, uint32_t nreads,
+                  uint32_t hdist_th, ko_result* out)
+{
+  memset(out, 0, sizeof(*out));
+  if (hdist_th > 16) return -1;
+  const uint32_t k = sk->k;
+  const Lsh& lsh = sk->lsh;
+  Llh llhfunc(sk->h, k, hdist_th);
+  const uint64_t u64m = std::numeric_limits<uint64_t>::max();
+  const uint64_t mask_lr = ((u64m >> (64 - k)) << 32) + ((u64m << 32) >> (64 - k));
+  const uint64_t mask_bp = u64m >> ((32 - k) * 2);
+  struct SSummary { // src/seek.hpp:18-40
+    double mismatch_count, match_count = 0, d_llh = NAN, v_llh = NAN;
+    std::vector<double> hdisthist_v;
+  };
+  auto check_partial = [&](uint32_t rix) { // src/sketch.hpp:18-22
+    const uint32_t rix_res = rix % sk->m;
+    return (sk->frac && (rix_res <= sk->r)) || (rix_res == sk->r);
+  };
+  auto add_matching_mer = [&](SSummary& su, uint32_t rix, uint32_t enc_lr) { // src/seek.cpp:104-121, src/sketch.cpp:35-39
+    const uint32_t rix_res = rix % sk->m;
+    const uint32_t offset = sk->frac ? (rix / sk->m) * (sk->r + 1) + rix_res : rix / sk->m;
+    uint64_t b0 = offset ? sk->inc_v[offset - 1] : 0, b1 = sk->inc_v[offset];
+    uint32_t hdist_min = hdist_th + 1;
+    for (; b0 < b1; ++b0) {
+      const uint32_t hdist_curr = popcount_lr32(sk->enc_v[b0] ^ enc_lr);
+      if (hdist_curr < hdist_min) hdist_min = hdist_curr;
+    }
+    if (hdist_min <= hdist_th) {
+      su.mismatch_count--;
+      su.match_count++;
+      su.hdisthist_v[hdist_min]++;
+    }
+  };
+  std::vector<ko_row> rows(nreads);
+  std::string text;
+  uint64_t ne = 0;
+  for (uint32_t bix = 0; bix < nreads; ++bix) {
+    const char* seq = bases + offsets[bix];
+    const uint64_t len = offsets[bix + 1] - offsets[bix];
+    uint64_t onmers = 0;
+    SSummary or_summary, rc_summary;
+    or_summary.mismatch_count = rc_summary.mismatch_count = (double)(len - k + 1);
+    or_summary.hdisthist_v.assign(hdist_th + 1, 0.0);
+    rc_summary.hdisthist_v.assign(hdist_th + 1, 0.0);
+    { // SBatch::search_mers (src/seek.cpp:58-102), non-CANONICAL build
+      uint32_t i, l;
+      uint64_t orenc64_bp = 0, orenc64_lr = 0, rcenc64_bp;
+      for (i = l = 0; i < len;) {
+        if (nt4((unsigned char)seq[i]) >= 4) {
+          l = 0, i++;
+          continue;
+        }
+        l++, i++;
+        if (l < k) continue;
+        if (l == k)
+          compute_encoding(seq + i - k, seq + i, orenc64_lr, orenc64_bp);
+        else
+          update_encoding(seq + i - 1, orenc64_lr, orenc64_bp);
+        orenc64_bp &= mask_bp;
+        orenc64_lr &= mask_lr;
+        rcenc64_bp = revcomp_bp64(orenc64_bp, k);
+        onmers++;
+        const uint32_t orrix = lsh.compute_hash(orenc64_bp);
+        if (check_partial(orrix)) add_matching_mer(or_summary, orrix, lsh.drop_ppos_lr(orenc64_lr));
+        const uint32_t rcrix = lsh.compute_hash(rcenc64_bp);
+        if (check_partial(rcrix)) add_matching_mer(rc_summary, rcrix, lsh.drop_ppos_lr(conv_bp64_lr64(rcenc64_bp)));
+      }
+    }
+    ko_row& row = rows[bix];
+    memset(&row, 0, sizeof(row));
+    row.read = bix;
+    const std::string id = names ? names[bix] : "";
+    if (or_summary.match_count + rc_summary.match_count) {
+      or_summary.mismatch_count = (double)onmers - or_summary.match_count;
+      rc_summary.mismatch_count = (double)onmers - rc_summary.match_count;
+      for (SSummary* su : {&or_summary, &rc_summary}) { // SSummary::optimize_likelihood (src/seek.cpp:122-128)
+        llhfunc.set_parameters(su->hdisthist_v.data(), su->mismatch_count, sk->rho);
+        auto sol = brent_find_minima(llhfunc, 1e-10, 0.5, 16, &ne);
+        su->d_llh = sol.first, su->v_llh = sol.second;
+      }
+      const SSummary& best = or_summary.d_llh < rc_summary.d_llh ? or_summary : rc_summary;
+      row.se = 1, row.d_llh = best.d_llh;
+      text += id + "\t" + Worker::f5(best.d_llh) + "\n";
+    } else {
+      row.d_llh = NAN;
+      text += id + "\tNaN\n";
+    }
+  }
+  out->nrows = nreads;
+  out->rows = dup_vec(rows);
+  out->text_len = text.size();
+  out->text = (char*)malloc(text.size() + 1);
+  memcpy(out->text, text.c_str(), text.size() + 1);
+  return 0;
+}
+
 } // extern "C"

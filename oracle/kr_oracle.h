@@ -171,6 +171,20 @@ int ko_place_batch(const ko_index*, const char* bases, const uint64_t* offsets, 
 /* which: 0 = text before the batches, 1 = text after them; caller frees with free() */
 char* ko_place_frame(const ko_index*, int which, int tabular, const char* invocation, uint64_t total_qseq);
 
+/* `krepp seek` on a single-reference sketch file (src/seek.cpp, src/sketch.cpp; file format
+ * SFlatHT::save src/table.cpp:34-40 + BaseLSH::save_configuration src/krepp.cpp:18-29 + rho).
+ * ko_seek_batch: out->text = `SEQ_ID\tDIST` / `SEQ_ID\tNaN` rows, out->rows one per read. */
+typedef struct ko_sketch ko_sketch;
+ko_sketch* ko_sketch_load(const char* path, char* err, int errlen);
+void ko_sketch_free(ko_sketch*);
+void ko_sketch_info(const ko_sketch*, uint64_t* nkmers, uint32_t* nrows, uint32_t* k, uint32_t* w, uint32_t* h, uint32_t* m,
+                    uint32_t* r, uint32_t* frac, double* rho /* scaled as make_rho_partial */);
+const uint32_t* ko_sketch_codes(const ko_sketch*);
+const uint64_t* ko_sketch_inc(const ko_sketch*);
+void ko_sketch_positions(const ko_sketch*, uint8_t* ppos, uint8_t* npos);
+int ko_seek_batch(const ko_sketch*, const char* bases, const uint64_t* offsets, const char* const* names, uint32_t nreads,
+                  uint32_t hdist_th, ko_result* out);
+
 /* Likelihood and minimiser, callable on their own
  * (src/hdhistllh.hpp:71-89, src/query.cpp:426-433). */
 double ko_llh(uint32_t k, uint32_t h, uint32_t th, const double* hist, double uc, double rho, double d);

@@ -85,6 +85,19 @@ def lib():
         l.ko_index_set_placement_tree.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int]
         l.ko_index_set_lineage_tree.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int]
         l.ko_place_summarize.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(KoParams), C.POINTER(KoResult)]
+        l.ko_sketch_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        l.ko_sketch_load.restype = vp
+        l.ko_sketch_free.argtypes = [vp]
+        l.ko_sketch_free.restype = None
+        l.ko_sketch_info.argtypes = [vp] + [vp] * 9
+        l.ko_sketch_info.restype = None
+        l.ko_sketch_codes.argtypes = [vp]
+        l.ko_sketch_codes.restype = C.POINTER(C.c_uint32)
+        l.ko_sketch_inc.argtypes = [vp]
+        l.ko_sketch_inc.restype = C.POINTER(C.c_uint64)
+        l.ko_sketch_positions.argtypes = [vp, vp, vp]
+        l.ko_sketch_positions.restype = None
+        l.ko_seek_batch.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(KoResult)]
         l.ko_place_batch.argtypes = [vp, vp, vp, vp, C.c_uint32, C.POINTER(KoParams), C.c_int, C.POINTER(KoResult)]
         l.ko_place_frame.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_uint64]
         l.ko_place_frame.restype = vp
@@ -289,3 +302,44 @@ def algorithmic_bytes(counters):
     c = counters
     return (c["bases"] + 16 * c["probes"] + 8 * c["bucket_entries"] + 8 * c["pse_reads"] + 8 * c["rho_reads"]
             + 16 * c["rows"])
+
+
+class Sketch:
+    """A `krepp sketch` file read by the oracle (src/sketch.cpp:3-39) and `krepp seek` on it (src/seek.cpp)."""
+
+    def __init__(self, path):
+        self.l = lib()
+        err = C.create_string_buffer(512)
+        self.h = self.l.ko_sketch_load(str(path).encode(), err, 512)
+        if not self.h:
+            raise RuntimeError("oracle: " + err.value.decode())
+        nk, nrows, k, w, h, m, r, frac = C.c_uint64(), *[C.c_uint32() for _ in range(7)]
+        rho = C.c_double()
+        self.l.ko_sketch_info(self.h, *[C.addressof(x) for x in (nk, nrows, k, w, h, m, r, frac, rho)])
+        self.nkmers, self.nrows, self.k, self.w, self.hh, self.m, self.r, self.frac = (
+            nk.value, nrows.value, k.value, w.value, h.value, m.value, r.value, frac.value)
+        self.rho = rho.value
+        self.codes = np.ctypeslib.as_array(self.l.ko_sketch_codes(self.h), shape=(self.nkmers,)).copy() if self.nkmers else np.zeros(0, np.uint32)
+        self.inc = np.ctypeslib.as_array(self.l.ko_sketch_inc(self.h), shape=(self.nrows,)).copy()
+        pp, npz = np.zeros(self.hh, np.uint8), np.zeros(self.k - self.hh, np.uint8)
+        self.l.ko_sketch_positions(self.h, pp.ctypes.data, npz.ctypes.data)
+        self.ppos, self.npos = pp, npz
+
+    def seek(self, bases, offsets, names=None, hdist_th=4):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        res = KoResult()
+        arr = (C.c_char_p * n)(*[s.encode() for s in names]) if names is not None else None
+        rc = self.l.ko_seek_batch(self.h, bases.ctypes.data, offsets.ctypes.data, arr, n, hdist_th, C.byref(res))
+        if rc:
+            raise RuntimeError(f"oracle ko_seek_batch rc={rc}")
+        rows = np.frombuffer(C.string_at(res.rows, res.nrows * ROW_DT.itemsize), dtype=ROW_DT).copy()
+        text = C.string_at(res.text, res.text_len).decode() if res.text_len else ""
+        self.l.ko_result_free(C.byref(res))
+        return dict(rows=rows, text=text)
+
+    def close(self):
+        if self.h:
+            self.l.ko_sketch_free(self.h)
+            self.h = None
