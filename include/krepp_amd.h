@@ -230,6 +230,10 @@ KR_API int kr_debug_brent(const kr_index*, uint32_t hdist_th, uint32_t n, const 
  * d_in[n] -> v_out (Minfo::likelihood_ratio's f(d), src/query.cpp:420-424). */
 KR_API int kr_llh_batch(const kr_index*, uint32_t hdist_th, uint32_t mode, uint64_t n, const double* hist, const double* uc,
                         const double* rho, const double* d_in, double* d_out, double* v_out);
+/* f_{problem pidx[i]}(d_in[i]), i < n: many evaluations of few problems (hist [nprob * (th + 1)], uc, rho [nprob]) --
+ * the chi-square tests of `place` (src/query.cpp:276, :420-424): every candidate of a read against its closest leaf. */
+KR_API int kr_llh_eval_indexed(const kr_index*, uint32_t th, uint64_t nprob, const double* hist, const double* uc, const double* rho,
+                               uint64_t n, const uint32_t* pidx, const double* d_in, double* v_out);
 
 /* Kernel timing of the last collected batch (HIP events on the stream's own stream). */
 typedef struct kr_timing {

@@ -87,7 +87,7 @@ EXPORTS = [
     "kr_index_upload", "kr_index_free", "kr_index_export", "kr_index_import", "kr_index_device_bytes",
     "kr_params_default", "kr_stream_create", "kr_stream_destroy", "kr_batch_submit", "kr_batch_wait",
     "kr_batch_collect", "kr_batch_collect_device", "kr_batch_hits", "kr_batch_readtaps",
-    "kr_debug_front_end", "kr_debug_brent", "kr_llh_batch", "kr_batch_timing",
+    "kr_debug_front_end", "kr_debug_brent", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
     "kr_place_tree_create", "kr_place_tree_create_lineage", "kr_place_tree_nnodes", "kr_place_summary_add",
     "kr_place_summary_text", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_frame",
     "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_format_dist", "kr_free",

@@ -4,6 +4,8 @@
 
 #include "krepp_amd.h"
 
+#include <cmath>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -57,6 +59,37 @@ inline int64_t build_row(uint32_t rix, const BuildCfg& c)
   if (c.frac ? res <= c.r : res == c.r) return c.frac ? (int64_t)(rix / c.m) * (c.r + 1) + res : (int64_t)(rix / c.m);
   return -1;
 }
+// "%.5f" of a value without going through printf: scale, round half away in integers.  printf rounds the
+// exact binary value; the two agree unless |v| * 1e5 lies within rounding noise of a tie (or v is out of the
+// fast range, NaN, infinite), where printf decides.  Checked against printf on 20 M random values.
+inline size_t fmt_fixed5(double v, char* out)
+{
+  const bool neg = std::signbit(v);
+  const double d = neg ? -v : v;
+  if (d >= 0.0 && d < 1000.0) {
+    const double sc = d * 100000.0, fl = std::floor(sc), fr = sc - fl;
+    if (std::fabs(fr - 0.5) > 1e-6) {
+      const uint64_t n = (uint64_t)fl + (fr > 0.5 ? 1u : 0u);
+      uint64_t ip = n / 100000u, fp = n % 100000u;
+      char tmp[8];
+      size_t k = 0, o = 0;
+      if (neg) out[o++] = '-';
+      do {
+        tmp[k++] = (char)('0' + ip % 10u);
+        ip /= 10u;
+      } while (ip);
+      while (k) out[o++] = tmp[--k];
+      out[o++] = '.';
+      for (int q = 4; q >= 0; --q) {
+        out[o + q] = (char)('0' + fp % 10u);
+        fp /= 10u;
+      }
+      return o + 5;
+    }
+  }
+  return (size_t)snprintf(out, 64, "%.5f", v);
+}
+
 inline uint64_t fmix64(uint64_t v)
 { // xur64_hash, src/common.hpp:147-155
   v ^= v >> 33;

@@ -45,6 +45,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -2429,18 +2430,20 @@ __global__ void kr_brent_kernel(LlhConst C, uint32_t n, const uint32_t* hist, co
   brent_min<NPT>(C, T, p, d_out[i], v_out[i]);
 }
 
+// pidx != nullptr: evaluation i uses problem pidx[i] (several evaluations of one histogram at different d)
 __global__ __launch_bounds__(256) void kr_llh_batch_kernel(LlhConst C, uint32_t mode, uint64_t n, const double* hist,
                                                            const double* uc, const double* rho, const double* d_in,
-                                                           double* d_out, double* v_out)
+                                                           double* d_out, double* v_out, const uint32_t* pidx)
 {
   __shared__ double s_bk[32], s_hnk[kMaxPlanes];
   LlhTables T{(lds_f64*)s_bk, (lds_f64*)s_hnk};
   llh_tables_init(C, T.bk, T.hnk);
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     LlhProblem p;
-    for (uint32_t x = 0; x <= C.th; ++x) p.mc[x] = hist[i * (C.th + 1) + x];
-    p.uc = uc[i];
-    p.rho = rho[i];
+    const uint64_t q = pidx ? pidx[i] : i;
+    for (uint32_t x = 0; x <= C.th; ++x) p.mc[x] = hist[q * (C.th + 1) + x];
+    p.uc = uc[q];
+    p.rho = rho[q];
     if (mode == 0) {
       double d, v;
       brent_min<0>(C, T, p, d, v);
@@ -2543,6 +2546,12 @@ struct kr_index {
   std::vector<kr_index_buffer> bufs; // export order
   std::vector<uint8_t> desc;    // export descriptor
   uint64_t bytes = 0;
+  // workspace of kr_llh_batch (grown on demand, reused across calls): one device buffer and one pinned host
+  // buffer laid out [hist n*np | uc n | rho n | d_in n | d_out n | v n]
+  mutable std::mutex llh_mu;
+  mutable double* llh_dev = nullptr;
+  mutable double* llh_pin = nullptr;
+  mutable uint64_t llh_cap = 0; // doubles
 };
 
 namespace {
@@ -2779,6 +2788,8 @@ void kr_index_free(kr_index* ix)
   if (!ix) return;
   (void)hipSetDevice(ix->device);
   for (void* p : ix->allocs) (void)hipFree(p);
+  if (ix->llh_dev) (void)hipFree(ix->llh_dev);
+  if (ix->llh_pin) (void)hipHostFree(ix->llh_pin);
   delete ix;
 }
 
@@ -3324,24 +3335,81 @@ int kr_llh_batch(const kr_index* ix, uint32_t th, uint32_t mode, uint64_t n, con
   if (n == 0) return KR_OK;
   HIP_TRY(hipSetDevice(ix->device));
   LlhConst C = make_llh_const(ix->dix.k, ix->dix.h, th);
-  double *d_h = nullptr, *d_uc = nullptr, *d_rho = nullptr, *d_di = nullptr, *d_do = nullptr, *d_v = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_h, n * (th + 1) * 8));
-  HIP_TRY(hipMalloc((void**)&d_uc, n * 8));
-  HIP_TRY(hipMalloc((void**)&d_rho, n * 8));
-  HIP_TRY(hipMalloc((void**)&d_di, n * 8));
-  HIP_TRY(hipMalloc((void**)&d_do, n * 8));
-  HIP_TRY(hipMalloc((void**)&d_v, n * 8));
-  HIP_TRY(hipMemcpy(d_h, hist, n * (th + 1) * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_uc, uc, n * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_rho, rho, n * 8, hipMemcpyHostToDevice));
-  if (mode == 1) HIP_TRY(hipMemcpy(d_di, d_in, n * 8, hipMemcpyHostToDevice));
+  const uint64_t np = th + 1, need = n * (np + 5);
+  std::lock_guard<std::mutex> lk(ix->llh_mu);
+  if (need > ix->llh_cap) {
+    if (ix->llh_dev) (void)hipFree(ix->llh_dev);
+    if (ix->llh_pin) (void)hipHostFree(ix->llh_pin);
+    ix->llh_dev = ix->llh_pin = nullptr, ix->llh_cap = 0;
+    const uint64_t cap = need + need / 4;
+    HIP_TRY(hipMalloc((void**)&ix->llh_dev, cap * 8));
+    HIP_TRY(hipHostMalloc((void**)&ix->llh_pin, cap * 8, hipHostMallocDefault));
+    ix->llh_cap = cap;
+  }
+  double *pin = ix->llh_pin, *dev = ix->llh_dev;
+  const uint64_t o_uc = n * np, o_rho = o_uc + n, o_di = o_rho + n, o_do = o_di + n, o_v = o_do + n;
+  { // stage the inputs in pinned memory (a few threads: tens of MB for a large batch), one H2D copy
+    const int nt = n >= (1u << 16) ? 4 : 1;
+    auto piece = [&](int t) {
+      const uint64_t a = n * (uint64_t)t / nt, b = n * (uint64_t)(t + 1) / nt;
+      memcpy(pin + a * np, hist + a * np, (b - a) * np * 8);
+      memcpy(pin + o_uc + a, uc + a, (b - a) * 8);
+      memcpy(pin + o_rho + a, rho + a, (b - a) * 8);
+      if (mode == 1) memcpy(pin + o_di + a, d_in + a, (b - a) * 8);
+    };
+    std::vector<std::thread> th_;
+    for (int t = 1; t < nt; ++t) th_.emplace_back(piece, t);
+    piece(0);
+    for (auto& t : th_) t.join();
+  }
+  HIP_TRY(hipMemcpy(dev, pin, (mode == 1 ? o_do : o_di) * 8, hipMemcpyHostToDevice));
   uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
-  hipLaunchKernelGGL(kr_llh_batch_kernel, dim3(grid), dim3(256), 0, 0, C, mode, n, d_h, d_uc, d_rho, d_di, d_do, d_v);
+  hipLaunchKernelGGL(kr_llh_batch_kernel, dim3(grid), dim3(256), 0, 0, C, mode, n, dev, dev + o_uc, dev + o_rho, dev + o_di, dev + o_do,
+                     dev + o_v, (const uint32_t*)nullptr);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
-  if (mode == 0) HIP_TRY(hipMemcpy(d_out, d_do, n * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(v_out, d_v, n * 8, hipMemcpyDeviceToHost));
-  (void)hipFree(d_h), (void)hipFree(d_uc), (void)hipFree(d_rho), (void)hipFree(d_di), (void)hipFree(d_do), (void)hipFree(d_v);
+  HIP_TRY(hipMemcpy(pin + o_do, dev + o_do, 2 * n * 8, hipMemcpyDeviceToHost)); // synchronises with the kernel (null stream)
+  if (mode == 0) memcpy(d_out, pin + o_do, n * 8);
+  memcpy(v_out, pin + o_v, n * 8);
+  return KR_OK;
+}
+
+// f_{problem pidx[i]}(d_in[i]) for i < n: many evaluations of few problems (the chi-square tests of `place`: every
+// candidate of a read against the read's closest leaf).  Workspace layout [hist nprob*np | uc | rho | d_in n | v n | pidx n].
+int kr_llh_eval_indexed(const kr_index* ix, uint32_t th, uint64_t nprob, const double* hist, const double* uc, const double* rho,
+                        uint64_t n, const uint32_t* pidx, const double* d_in, double* v_out)
+{
+  kr::clear_error();
+  if (!ix || th > KR_MAX_HDIST_TH || (n && (!hist || !uc || !rho || !pidx || !d_in || !v_out || !nprob)))
+    return kr::fail(KR_ERR_ARG, "kr_llh_eval_indexed: bad argument");
+  if (n == 0) return KR_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  LlhConst C = make_llh_const(ix->dix.k, ix->dix.h, th);
+  const uint64_t np = th + 1, o_uc = nprob * np, o_rho = o_uc + nprob, o_di = o_rho + nprob, o_v = o_di + n, o_ix = o_v + n,
+                 need = o_ix + (n + 1) / 2;
+  std::lock_guard<std::mutex> lk(ix->llh_mu);
+  if (need > ix->llh_cap) {
+    if (ix->llh_dev) (void)hipFree(ix->llh_dev);
+    if (ix->llh_pin) (void)hipHostFree(ix->llh_pin);
+    ix->llh_dev = ix->llh_pin = nullptr, ix->llh_cap = 0;
+    const uint64_t cap = need + need / 4;
+    HIP_TRY(hipMalloc((void**)&ix->llh_dev, cap * 8));
+    HIP_TRY(hipHostMalloc((void**)&ix->llh_pin, cap * 8, hipHostMallocDefault));
+    ix->llh_cap = cap;
+  }
+  double *pin = ix->llh_pin, *dev = ix->llh_dev;
+  memcpy(pin, hist, nprob * np * 8);
+  memcpy(pin + o_uc, uc, nprob * 8);
+  memcpy(pin + o_rho, rho, nprob * 8);
+  memcpy(pin + o_di, d_in, n * 8);
+  memcpy(pin + o_ix, pidx, n * 4);
+  HIP_TRY(hipMemcpy(dev, pin, o_v * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dev + o_ix, pin + o_ix, n * 4, hipMemcpyHostToDevice));
+  uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(kr_llh_batch_kernel, dim3(grid), dim3(256), 0, 0, C, 1u, n, dev, dev + o_uc, dev + o_rho, dev + o_di, (double*)nullptr,
+                     dev + o_v, (const uint32_t*)(dev + o_ix));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(pin + o_v, dev + o_v, n * 8, hipMemcpyDeviceToHost));
+  memcpy(v_out, pin + o_v, n * 8);
   return KR_OK;
 }
 

@@ -1035,32 +1035,7 @@ void kr_fastx_close(kr_fastx* r)
 
 // report_distances (src/query.cpp:158-196), non-summarize branch.  The selection
 // (multi / filter / dist-max / closest) was already made on the device: rec_sel.
-// "%.5f" of a distance without going through printf: scale, round half away in integers.  printf rounds the
-// exact binary value; the two agree unless d * 1e5 lies within rounding noise of a tie, where printf decides.
-static inline size_t fmt_fixed5(double d, char* out)
-{
-  if (d >= 0.0 && d < 1000.0) {
-    const double sc = d * 100000.0, fl = std::floor(sc), fr = sc - fl;
-    if (std::fabs(fr - 0.5) > 1e-6) {
-      const uint64_t n = (uint64_t)fl + (fr > 0.5 ? 1u : 0u);
-      uint64_t ip = n / 100000u, fp = n % 100000u;
-      char tmp[8];
-      size_t k = 0, o = 0;
-      do {
-        tmp[k++] = (char)('0' + ip % 10u);
-        ip /= 10u;
-      } while (ip);
-      while (k) out[o++] = tmp[--k];
-      out[o++] = '.';
-      for (int q = 4; q >= 0; --q) {
-        out[o + q] = (char)('0' + fp % 10u);
-        fp /= 10u;
-      }
-      return o + 5;
-    }
-  }
-  return (size_t)snprintf(out, 64, "%.5f", d);
-}
+using kr::fmt_fixed5;
 
 int kr_format_dist(const kr_host_index* h, const kr_result_view* rv, const char* const* names, char** text,
                    uint64_t* len)

@@ -15,9 +15,12 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <omp.h>
 #include <string>
 #include <vector>
 
@@ -57,27 +60,41 @@ void nwk_jplace(const kr_place_tree& pt, uint32_t se, std::string& o)
   if (se == pt.root) o += ";";
 }
 
+constexpr uint32_t kMaxNp = 17; // hdist_th <= 16
+
 struct Acc { // the fields of Minfo that placement needs
   double nmers = 0, mismatch = 0, match = 0, rho = 0;
-  std::vector<double> hist;
+  double hist[kMaxNp];
   double d = 1.7976931348623157e308, v = NAN, chisq = NAN, lwr = 1;
   bool leaf = false;
-  void add(const Acc& m, double denom)
+  void zero(uint32_t np)
+  {
+    nmers = mismatch = match = rho = 0;
+    for (uint32_t x = 0; x < np; ++x) hist[x] = 0;
+    d = 1.7976931348623157e308, v = NAN, chisq = NAN, lwr = 1, leaf = false;
+  }
+  void add(const Acc& m, double denom, uint32_t np)
   { // Minfo::add (src/query.hpp:139-152)
     mismatch = nmers ? mismatch : m.nmers;
     match += m.match * denom;
     mismatch -= m.match * denom;
-    for (size_t x = 0; x < hist.size(); ++x) hist[x] = hist[x] + m.hist[x] * denom;
+    for (uint32_t x = 0; x < np; ++x) hist[x] = hist[x] + m.hist[x] * denom;
     nmers = std::max(nmers, m.nmers);
     rho = std::max(rho, m.rho);
   }
-  double leq_tau(uint32_t tau) const
+  double leq_tau(uint32_t tau, uint32_t np) const
   {
     double s = 0;
-    for (uint32_t x = 0; x <= tau && x < hist.size(); ++x) s += hist[x];
+    for (uint32_t x = 0; x <= tau && x < np; ++x) s += hist[x];
     return s;
   }
   double jc() const { return -0.75 * log(1 - 4.0 / 3.0 * d); }
+};
+
+struct Cand {
+  uint32_t read, se; // placement-tree node
+  Acc a;
+  bool internal;
 };
 
 void map_leaves(const kr_host_index* hx, const kr_index_view& v, kr_place_tree& pt);
@@ -359,205 +376,318 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
   const uint32_t np = p->hdist_th + 1, th = p->hdist_th, k = iv.k;
   const double* rho_tab = iv.libs[0].rho;
 
-  // ---- phase A (host): per read, the leaf set, the closest, ancestor accumulation, candidates
-  struct Cand {
-    uint32_t read, se; // placement-tree node
-    Acc a;
-    bool internal;
+  const bool timing = getenv("KR_PLACE_TIMING") != nullptr;
+  double t_mark = omp_get_wtime();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const double now = omp_get_wtime();
+    fprintf(stderr, "[place] %s %.1f ms\n", what, (now - t_mark) * 1e3);
+    t_mark = now;
   };
+  // ---- phase A (host, one OpenMP thread per range of reads): per read, the leaf set, the closest, ancestor
+  //      accumulation, candidates.  Each thread keeps a small open-addressing table node -> accumulator that
+  //      is reused from read to read (stamps instead of clearing).
   struct ReadPlan {
     bool reported = false, single = false;
-    size_t c0 = 0, c1 = 0; // candidate range
-    Acc closest;
+    size_t c0 = 0, c1 = 0; // candidate range in `cands`
+    int closest = -1;      // index into `closest_acc`
     uint32_t closest_pt = 0;
   };
   std::vector<ReadPlan> plan(rv->nreads);
-  std::vector<Cand> cands;
-  for (uint32_t r = 0; r < rv->nreads; ++r) {
-    const uint32_t o = rv->read_off[r], n = rv->read_cnt[r];
-    if (n == 0) continue;
-    const double enmers = (double)((offsets[r + 1] - offsets[r]) >= k ? (offsets[r + 1] - offsets[r]) - k + 1 : 0);
-    auto leaf_acc = [&](uint32_t i) {
-      Acc a;
-      a.leaf = true;
-      a.hist.resize(np);
-      double mc = 0;
-      for (uint32_t x = 0; x < np; ++x) a.hist[x] = rv->rec_hist[(uint64_t)x * rv->rec_hist_stride + i], mc += a.hist[x];
-      a.match = mc;
-      a.mismatch = (double)rv->read_onmers[r] - mc; // src/query.cpp:104
-      a.nmers = enmers;                              // IMers::enmers (src/query.cpp:335-350)
-      a.rho = rho_tab[rv->rec_key[i] >> 1];
-      a.d = rv->rec_d[i], a.v = rv->rec_v[i];
-      return a;
-    };
-    // closest: last record in (strand, se) order with d <= best (summarize_matches' `<=`, as in the oracle)
-    double best = 1.7976931348623157e308;
-    int cl = -1;
-    for (int strand = 0; strand < 2; ++strand)
-      for (uint32_t i = o; i < o + n; ++i)
-        if (rv->rec_key[i] && (rv->rec_key[i] & 1u) == (uint32_t)strand && rv->rec_d[i] <= best) best = rv->rec_d[i], cl = (int)i;
-    if (cl < 0) continue;
-    ReadPlan& pl = plan[r];
-    pl.closest = leaf_acc((uint32_t)cl);
-    pl.closest_pt = pt->idx_to_pt[rv->rec_key[cl] >> 1];
-    if (!(p->no_filter || pl.closest.leq_tau(p->tau) > 1.0)) continue; // src/query.cpp:220
-    // node_to_minfo: the record chosen for each leaf (rec_sel under multi / no_filter / no dist-max)
-    std::map<uint32_t, Acc> pp; // keyed by placement-tree se: ascending edge order
-    uint32_t nleaf = 0;
-    for (uint32_t i = o; i < o + n; ++i)
-      if (rv->rec_sel[i]) {
-        uint32_t q = pt->idx_to_pt[rv->rec_key[i] >> 1];
-        if (!q) continue;
-        pp[q] = leaf_acc(i);
-        nleaf++;
-      }
-    if (nleaf == 0) continue;
-    pl.reported = true;
-    pl.c0 = cands.size();
-    pl.closest.chisq = 0;
-    if (nleaf == 1) { // src/query.cpp:233-244
-      pl.single = true;
-      cands.push_back(Cand{r, pl.closest_pt, pl.closest, false});
-      pl.c1 = cands.size();
-      continue;
-    }
-    std::vector<uint32_t> leaves;
-    for (auto& kv : pp) leaves.push_back(kv.first);
-    for (uint32_t lf : leaves) { // src/query.cpp:250-267
-      const Acc src = pp[lf];
-      double denom = 1.0;
-      uint32_t par = lf;
-      while ((par = pt->t.nodes[par].parent)) {
-        denom /= pt->eff[par];
-        auto it = pp.find(par);
-        if (it == pp.end()) {
-          Acc z;
-          z.hist.assign(np, 0.0);
-          it = pp.emplace(par, z).first;
+  const int nt = rv->nreads >= 2048 ? std::max(1, std::min(omp_get_max_threads(), 32)) : 1;
+  struct ThreadOut {
+    std::vector<Cand> cands;
+    std::vector<Acc> closest;
+  };
+  std::vector<ThreadOut> tout((size_t)nt);
+#pragma omp parallel for num_threads(nt) schedule(static, 1)
+  for (int t = 0; t < nt; ++t) {
+    ThreadOut& T = tout[(size_t)t];
+    const uint32_t ra = (uint32_t)((uint64_t)rv->nreads * t / nt), rb = (uint32_t)((uint64_t)rv->nreads * (t + 1) / nt);
+    std::vector<uint32_t> tkey(256), tval(256), tstamp(256, 0);
+    uint32_t stamp = 0;
+    std::vector<Acc> pool;
+    std::vector<std::pair<uint32_t, uint32_t>> entries, leaves; // (node, pool index)
+    auto find_or_add = [&](uint32_t node) -> uint32_t {
+      for (;;) {
+        const uint32_t mask = (uint32_t)tkey.size() - 1;
+        uint32_t hsl = (node * 2654435761u) & mask;
+        while (tstamp[hsl] == stamp && tkey[hsl] != node) hsl = (hsl + 1) & mask;
+        if (tstamp[hsl] == stamp) return tval[hsl];
+        if (2 * (entries.size() + 1) > tkey.size()) { // grow, re-insert
+          const size_t ncap = tkey.size() * 2;
+          tkey.assign(ncap, 0), tval.assign(ncap, 0), tstamp.assign(ncap, 0);
+          stamp = 1;
+          for (auto& e : entries) {
+            uint32_t q = (e.first * 2654435761u) & (uint32_t)(ncap - 1);
+            while (tstamp[q] == stamp) q = (q + 1) & (uint32_t)(ncap - 1);
+            tstamp[q] = stamp, tkey[q] = e.first, tval[q] = e.second;
+          }
+          continue;
         }
-        it->second.add(src, denom);
+        tstamp[hsl] = stamp, tkey[hsl] = node, tval[hsl] = (uint32_t)pool.size();
+        entries.emplace_back(node, (uint32_t)pool.size());
+        pool.emplace_back();
+        pool.back().zero(np);
+        return tval[hsl];
       }
+    };
+    for (uint32_t r = ra; r < rb; ++r) {
+      const uint32_t o = rv->read_off[r], n = rv->read_cnt[r];
+      if (n == 0) continue;
+      const double enmers = (double)((offsets[r + 1] - offsets[r]) >= k ? (offsets[r + 1] - offsets[r]) - k + 1 : 0);
+      auto leaf_acc = [&](uint32_t i, Acc& a) {
+        a.zero(np);
+        a.leaf = true;
+        double mc = 0;
+        for (uint32_t x = 0; x < np; ++x) a.hist[x] = rv->rec_hist[(uint64_t)x * rv->rec_hist_stride + i], mc += a.hist[x];
+        a.match = mc;
+        a.mismatch = (double)rv->read_onmers[r] - mc; // src/query.cpp:104
+        a.nmers = enmers;                              // IMers::enmers (src/query.cpp:335-350)
+        a.rho = rho_tab[rv->rec_key[i] >> 1];
+        a.d = rv->rec_d[i], a.v = rv->rec_v[i];
+      };
+      // closest: last record in (strand, se) order with d <= best (summarize_matches' `<=`, as in the oracle)
+      double best = 1.7976931348623157e308;
+      int cl = -1;
+      for (int strand = 0; strand < 2; ++strand)
+        for (uint32_t i = o; i < o + n; ++i)
+          if (rv->rec_key[i] && (rv->rec_key[i] & 1u) == (uint32_t)strand && rv->rec_d[i] <= best) best = rv->rec_d[i], cl = (int)i;
+      if (cl < 0) continue;
+      ReadPlan& pl = plan[r];
+      Acc closest;
+      leaf_acc((uint32_t)cl, closest);
+      pl.closest_pt = pt->idx_to_pt[rv->rec_key[cl] >> 1];
+      if (!(p->no_filter || closest.leq_tau(p->tau, np) > 1.0)) continue; // src/query.cpp:220
+      // node_to_minfo: the record chosen for each leaf (rec_sel under multi / no_filter / no dist-max)
+      ++stamp;
+      if (stamp == 0) std::fill(tstamp.begin(), tstamp.end(), 0u), stamp = 1;
+      pool.clear(), entries.clear(), leaves.clear();
+      for (uint32_t i = o; i < o + n; ++i)
+        if (rv->rec_sel[i]) {
+          const uint32_t q = pt->idx_to_pt[rv->rec_key[i] >> 1];
+          if (!q) continue;
+          const uint32_t slot = find_or_add(q);
+          leaf_acc(i, pool[slot]);
+        }
+      if (entries.empty()) continue;
+      pl.reported = true;
+      pl.c0 = T.cands.size();
+      closest.chisq = 0;
+      pl.closest = (int)T.closest.size();
+      T.closest.push_back(closest);
+      if (entries.size() == 1) { // src/query.cpp:233-244
+        pl.single = true;
+        T.cands.push_back(Cand{r, pl.closest_pt, closest, false});
+        pl.c1 = T.cands.size();
+        continue;
+      }
+      leaves = entries;
+      std::sort(leaves.begin(), leaves.end()); // ascending edge number: the order the sums are formed in
+      for (auto& lf : leaves) { // src/query.cpp:250-267
+        const Acc src = pool[lf.second];
+        double denom = 1.0;
+        uint32_t par = lf.first;
+        while ((par = pt->t.nodes[par].parent)) {
+          denom /= pt->eff[par];
+          pool[find_or_add(par)].add(src, denom, np);
+        }
+      }
+      std::sort(entries.begin(), entries.end());
+      for (auto& e : entries) { // src/query.cpp:270-283 (likelihoods deferred to the GPU)
+        const uint32_t q = e.first;
+        const Acc& a = pool[e.second];
+        const uint32_t nch = (uint32_t)pt->kids[q].size();
+        if (nch != pt->eff[q] || nch == 1) continue;
+        if (p->no_filter || a.leq_tau(p->tau, np) > 1.0) T.cands.push_back(Cand{r, q, a, !a.leaf});
+      }
+      pl.c1 = T.cands.size();
     }
-    for (auto& kv : pp) { // src/query.cpp:270-283 (likelihoods deferred to the GPU)
-      uint32_t q = kv.first;
-      uint32_t nch = (uint32_t)pt->kids[q].size();
-      if (nch != pt->eff[q] || nch == 1) continue;
-      if (p->no_filter || kv.second.leq_tau(p->tau) > 1.0) cands.push_back(Cand{r, q, kv.second, !kv.second.leaf});
-    }
-    pl.c1 = cands.size();
   }
-
+  lap("A: aggregation");
+  // one candidate list in read order: pointers into the threads' vectors
+  std::vector<Cand*> cands;
+  std::vector<size_t> cbase((size_t)nt + 1, 0), lbase((size_t)nt + 1, 0);
+  for (int t = 0; t < nt; ++t) cbase[(size_t)t + 1] = cbase[(size_t)t] + tout[(size_t)t].cands.size(), lbase[(size_t)t + 1] = lbase[(size_t)t] + tout[(size_t)t].closest.size();
+  cands.resize(cbase[(size_t)nt]);
+  std::vector<const Acc*> closest_acc(lbase[(size_t)nt]);
+#pragma omp parallel for num_threads(nt) schedule(static, 1)
+  for (int t = 0; t < nt; ++t) {
+    const uint32_t ra = (uint32_t)((uint64_t)rv->nreads * t / nt), rb = (uint32_t)((uint64_t)rv->nreads * (t + 1) / nt);
+    const size_t cb = cbase[(size_t)t], lb = lbase[(size_t)t];
+    for (uint32_t r = ra; r < rb; ++r)
+      if (plan[r].reported) plan[r].c0 += cb, plan[r].c1 += cb, plan[r].closest += (int)lb;
+    ThreadOut& T = tout[(size_t)t];
+    for (size_t q = 0; q < T.cands.size(); ++q) cands[cb + q] = &T.cands[q];
+    for (size_t q = 0; q < T.closest.size(); ++q) closest_acc[lb + q] = &T.closest[q];
+  }
+  lap("A: merge");
   // ---- phase B (GPU): Brent on the internal candidates
   {
     std::vector<size_t> which;
     for (size_t i = 0; i < cands.size(); ++i)
-      if (cands[i].internal) which.push_back(i);
+      if (cands[i]->internal) which.push_back(i);
     std::vector<double> hist(which.size() * np), uc(which.size()), rho(which.size()), d(which.size()), v(which.size());
+#pragma omp parallel for num_threads(nt) schedule(static)
     for (size_t j = 0; j < which.size(); ++j) {
-      const Acc& a = cands[which[j]].a;
+      const Acc& a = cands[which[j]]->a;
       for (uint32_t x = 0; x < np; ++x) hist[j * np + x] = a.hist[x];
       uc[j] = a.mismatch, rho[j] = a.rho;
     }
     int rc = kr_llh_batch(dix, th, 0, which.size(), hist.data(), uc.data(), rho.data(), nullptr, d.data(), v.data());
     if (rc) return rc;
-    for (size_t j = 0; j < which.size(); ++j) cands[which[j]].a.d = d[j], cands[which[j]].a.v = v[j];
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (size_t j = 0; j < which.size(); ++j) cands[which[j]]->a.d = d[j], cands[which[j]]->a.v = v[j];
   }
-  // ---- phase C (GPU): chisq = 2 * (f_closest(d_candidate) - v_closest)   (src/query.cpp:276, :420-424)
+  lap("B: Brent on internal candidates");
+  // ---- phase C (GPU): chisq = 2 * (f_closest(d_candidate) - v_closest)   (src/query.cpp:276, :420-424): one problem per
+  //      read (its closest leaf), one evaluation per candidate
   {
     std::vector<size_t> which;
     for (size_t i = 0; i < cands.size(); ++i)
-      if (!plan[cands[i].read].single) which.push_back(i);
-    std::vector<double> hist(which.size() * np), uc(which.size()), rho(which.size()), din(which.size()), f(which.size());
-    for (size_t j = 0; j < which.size(); ++j) {
-      const Acc& c = plan[cands[which[j]].read].closest;
-      for (uint32_t x = 0; x < np; ++x) hist[j * np + x] = c.hist[x];
-      uc[j] = c.mismatch, rho[j] = c.rho, din[j] = cands[which[j]].a.d;
+      if (!plan[cands[i]->read].single) which.push_back(i);
+    const size_t nprob = closest_acc.size(), nev = which.size();
+    std::unique_ptr<double[]> hist(new double[std::max<size_t>(1, nprob * np)]), uc(new double[std::max<size_t>(1, nprob)]),
+      rho(new double[std::max<size_t>(1, nprob)]), din(new double[std::max<size_t>(1, nev)]), f(new double[std::max<size_t>(1, nev)]);
+    std::unique_ptr<uint32_t[]> pidx(new uint32_t[std::max<size_t>(1, nev)]);
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (size_t q = 0; q < nprob; ++q) {
+      const Acc& c = *closest_acc[q];
+      for (uint32_t x = 0; x < np; ++x) hist[q * np + x] = c.hist[x];
+      uc[q] = c.mismatch, rho[q] = c.rho;
     }
-    int rc = kr_llh_batch(dix, th, 1, which.size(), hist.data(), uc.data(), rho.data(), din.data(), nullptr, f.data());
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (size_t j = 0; j < nev; ++j) pidx[j] = (uint32_t)plan[cands[which[j]]->read].closest, din[j] = cands[which[j]]->a.d;
+    int rc = kr_llh_eval_indexed(dix, th, nprob, hist.get(), uc.get(), rho.get(), nev, pidx.get(), din.get(), f.get());
     if (rc) return rc;
-    for (size_t j = 0; j < which.size(); ++j) {
-      Cand& c = cands[which[j]];
-      c.a.chisq = 2 * (f[j] - plan[c.read].closest.v);
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (size_t j = 0; j < nev; ++j) {
+      Cand& c = *cands[which[j]];
+      c.a.chisq = 2 * (f[j] - closest_acc[(size_t)plan[c.read].closest]->v);
     }
   }
-
-  // ---- phase D (host): candidate filter, LWR, text
-  std::string out;
-  std::vector<kr_placement> pls;
-  bool prev = *has_previous != 0;
+  lap("C: chi-square evaluations");
+  // ---- phase D (host, the same read ranges in parallel): candidate filter, LWR, text; pieces joined in order
   auto en = [&](uint32_t q) { return q - 1; };
   auto mid = [&](uint32_t q) { return std::isnan(pt->t.nodes[q].blen) ? 0.0 : pt->t.nodes[q].blen / 2.0; };
-  auto jfields = [&](uint32_t q, const Acc& a) {
-    return "[" + std::to_string(en(q)) + ", " + f5(a.jc() - mid(q)) + ", " + f5(mid(q)) + ", " + f5(-a.v) + ", " + f5(a.lwr) + ", " +
-           f5(a.d) + "]";
+  auto num = [](std::string& o, double v) {
+    char b[64];
+    if (std::isnan(v)) {
+      o += std::signbit(v) ? "-nan" : "nan";
+      return;
+    }
+    o.append(b, kr::fmt_fixed5(v, b));
   };
-  auto tfields = [&](uint32_t q, const Acc& a) {
+  auto jfields = [&](std::string& o, uint32_t q, const Acc& a) {
+    o += '[';
+    o += std::to_string(en(q));
+    o += ", ", num(o, a.jc() - mid(q));
+    o += ", ", num(o, mid(q));
+    o += ", ", num(o, -a.v);
+    o += ", ", num(o, a.lwr);
+    o += ", ", num(o, a.d);
+    o += ']';
+  };
+  auto tfields = [&](std::string& o, uint32_t q, const Acc& a) {
     const std::string& nm = pt->t.nodes[q].label;
-    return (nm.empty() ? std::string("NA") : nm) + "\t" + std::to_string(en(q)) + "\t" + f5(a.lwr) + "\t" + f5(a.d);
-  };
-  auto record = [&](uint32_t r, uint32_t q, const Acc& a) {
-    kr_placement x;
-    x.read = r, x.edge = en(q), x.lwr = a.lwr, x.d_llh = a.d, x.v_llh = a.v, x.pendant = a.jc() - mid(q), x.distal = mid(q);
-    pls.push_back(x);
+    o += nm.empty() ? std::string("NA") : nm;
+    o += '\t';
+    o += std::to_string(en(q));
+    o += '\t', num(o, a.lwr);
+    o += '\t', num(o, a.d);
   };
   const bool jp = tabular == 0, tb = tabular == 1; // 2: --summarize, no text (the caller sums the placements)
-  for (uint32_t r = 0; r < rv->nreads; ++r) {
-    ReadPlan& pl = plan[r];
-    if (!pl.reported) continue;
-    std::string id = names ? names[r] : "";
-    if (jp) {
-      if (prev) out += ",\n";
-      out += "\t\t\t{\"n\" : [\"" + id + "\"], \"p\" : [";
-      prev = true;
-    }
-    if (pl.single) {
-      Cand& c = cands[pl.c0];
-      record(r, c.se, c.a);
-      if (tb)
-        out += id + "\t" + tfields(c.se, c.a) + "\n";
-      else if (jp)
-        out += jfields(c.se, c.a) + "]}";
-      continue;
-    }
+  std::vector<std::string> part((size_t)nt);
+  std::vector<std::vector<kr_placement>> ppls((size_t)nt);
+#pragma omp parallel for num_threads(nt) schedule(static, 1)
+  for (int t = 0; t < nt; ++t) {
+    const uint32_t ra = (uint32_t)((uint64_t)rv->nreads * t / nt), rb = (uint32_t)((uint64_t)rv->nreads * (t + 1) / nt);
+    std::string& out = part[(size_t)t];
+    std::vector<kr_placement>& pls = ppls[(size_t)t];
+    bool prev = false; // within the piece; pieces are joined with the separator below
+    auto record = [&](uint32_t r, uint32_t q, const Acc& a) {
+      kr_placement x;
+      x.read = r, x.edge = en(q), x.lwr = a.lwr, x.d_llh = a.d, x.v_llh = a.v, x.pendant = a.jc() - mid(q), x.distal = mid(q);
+      pls.push_back(x);
+    };
     std::vector<size_t> nd_v;
-    for (size_t i = pl.c0; i < pl.c1; ++i)
-      if (cands[i].a.chisq < p->chisq && pt->t.nodes[cands[i].se].parent) nd_v.push_back(i);
-    double total = 0;
-    for (size_t i : nd_v) {
-      cands[i].a.lwr = exp(-cands[i].a.chisq / 2);
-      total = total + cands[i].a.lwr;
-    }
-    if (p->multi) {
-      for (size_t j = 0; j < nd_v.size(); ++j) {
-        Cand& c = cands[nd_v[j]];
-        c.a.lwr = c.a.lwr / total;
-        record(r, c.se, c.a);
-        if (j > 0 && jp) out += ",";
-        if (tb)
-          out += id + "\t" + tfields(c.se, c.a) + "\n";
-        else if (jp)
-          out += "\n\t\t\t\t" + jfields(c.se, c.a);
+    for (uint32_t r = ra; r < rb; ++r) {
+      ReadPlan& pl = plan[r];
+      if (!pl.reported) continue;
+      const char* id = names ? names[r] : "";
+      if (jp) {
+        if (prev) out += ",\n";
+        out += "\t\t\t{\"n\" : [\"";
+        out += id;
+        out += "\"], \"p\" : [";
+        prev = true;
       }
-      if (jp) out += "]\n\t\t\t}";
-    } else {
-      if (nd_v.size() > 1)
-        std::stable_sort(nd_v.begin(), nd_v.end(), [&](size_t l, size_t rr) {
-          uint32_t cl_ = pt->card[cands[l].se], cr = pt->card[cands[rr].se];
-          return cl_ == cr ? cands[l].a.d > cands[rr].a.d : cl_ < cr;
-        });
-      if (nd_v.empty()) {
-        if (jp) out += "]}";
+      if (pl.single) {
+        Cand& c = *cands[pl.c0];
+        record(r, c.se, c.a);
+        if (tb)
+          out += id, out += '\t', tfields(out, c.se, c.a), out += '\n';
+        else if (jp)
+          jfields(out, c.se, c.a), out += "]}";
         continue;
       }
-      Cand& c = cands[nd_v.back()];
-      c.a.lwr = c.a.lwr / total;
-      record(r, c.se, c.a);
-      if (tb)
-        out += id + "\t" + tfields(c.se, c.a) + "\n";
-      else if (jp)
-        out += jfields(c.se, c.a) + "]}";
+      nd_v.clear();
+      for (size_t i = pl.c0; i < pl.c1; ++i)
+        if (cands[i]->a.chisq < p->chisq && pt->t.nodes[cands[i]->se].parent) nd_v.push_back(i);
+      double total = 0;
+      for (size_t i : nd_v) {
+        cands[i]->a.lwr = exp(-cands[i]->a.chisq / 2);
+        total = total + cands[i]->a.lwr;
+      }
+      if (p->multi) {
+        for (size_t j2 = 0; j2 < nd_v.size(); ++j2) {
+          Cand& c = *cands[nd_v[j2]];
+          c.a.lwr = c.a.lwr / total;
+          record(r, c.se, c.a);
+          if (j2 > 0 && jp) out += ",";
+          if (tb)
+            out += id, out += '\t', tfields(out, c.se, c.a), out += '\n';
+          else if (jp)
+            out += "\n\t\t\t\t", jfields(out, c.se, c.a);
+        }
+        if (jp) out += "]\n\t\t\t}";
+      } else {
+        if (nd_v.size() > 1)
+          std::stable_sort(nd_v.begin(), nd_v.end(), [&](size_t l, size_t rr) {
+            uint32_t cl_ = pt->card[cands[l]->se], cr = pt->card[cands[rr]->se];
+            return cl_ == cr ? cands[l]->a.d > cands[rr]->a.d : cl_ < cr;
+          });
+        if (nd_v.empty()) {
+          if (jp) out += "]}";
+          continue;
+        }
+        Cand& c = *cands[nd_v.back()];
+        c.a.lwr = c.a.lwr / total;
+        record(r, c.se, c.a);
+        if (tb)
+          out += id, out += '\t', tfields(out, c.se, c.a), out += '\n';
+        else if (jp)
+          jfields(out, c.se, c.a), out += "]}";
+      }
     }
   }
+  lap("D: filter + text");
+  bool prev = *has_previous != 0;
+  size_t total_len = 0, total_pl = 0;
+  for (int t = 0; t < nt; ++t) total_len += part[(size_t)t].size() + 2, total_pl += ppls[(size_t)t].size();
+  std::string out;
+  out.reserve(total_len);
+  std::vector<kr_placement> pls;
+  pls.reserve(total_pl);
+  for (int t = 0; t < nt; ++t) {
+    if (!part[(size_t)t].empty()) {
+      if (jp && prev) out += ",\n";
+      out += part[(size_t)t];
+      if (jp) prev = true;
+    }
+    pls.insert(pls.end(), ppls[(size_t)t].begin(), ppls[(size_t)t].end());
+  }
+  lap("D: join");
   *has_previous = prev ? 1 : 0;
   *text = dup_text(out, len);
   if (!*text) return kr::fail(KR_ERR_NOMEM, "kr_place_batch: out of memory");
