@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,12 @@ struct HostTree {
 
 bool parse_newick(const std::string& text, HostTree& out, std::string& err);
 void balanced_tree(const std::vector<std::string>& names, HostTree& out);
+
+// f(0) ... f(n-1) on a process-wide pool of sleeping threads (condition variables, no spinning: several callers
+// -- the CLI's workers -- share the cores; OpenMP teams that busy-wait between regions cost 2x here).  The caller
+// runs pieces too; returns when all are done.
+void parallel_for(int n, const std::function<void(int)>& f);
+int parallel_width(); // threads worth asking for (pool size + 1)
 
 // MurmurHash3_x86_32 based 64-bit name hash (src/record.hpp:26-36)
 uint64_t leaf_name_hash(const std::string& name);

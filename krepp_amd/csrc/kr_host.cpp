@@ -285,6 +285,105 @@ void balanced_tree(const std::vector<std::string>& names, HostTree& out)
 // ---------------------------------------------------------------------------
 // kr_host_index
 // ---------------------------------------------------------------------------
+namespace kr {
+namespace {
+struct Pool {
+  struct Call {
+    const std::function<void(int)>* f;
+    int n, next = 0, done = 0;
+  };
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::deque<Call*> calls; // calls with pieces left to hand out
+  std::vector<std::thread> threads;
+  bool stop = false;
+  Pool()
+  {
+    const char* e = getenv("KR_HOST_THREADS");
+    unsigned nt = e ? (unsigned)atoi(e) : std::min(31u, std::max(1u, std::thread::hardware_concurrency() / 4));
+    for (unsigned t = 0; t < nt; ++t) threads.emplace_back([this] { run(); });
+  }
+  ~Pool()
+  {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_work.notify_all();
+    for (auto& t : threads) t.join();
+  }
+  // take one piece of the front call (lock held); returns false if there is none
+  bool take(Call*& c, int& i)
+  {
+    while (!calls.empty() && calls.front()->next >= calls.front()->n) calls.pop_front();
+    if (calls.empty()) return false;
+    c = calls.front();
+    i = c->next++;
+    return true;
+  }
+  void finish(Call* c)
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (++c->done == c->n) cv_done.notify_all();
+  }
+  void run()
+  {
+    for (;;) {
+      Call* c = nullptr;
+      int i = 0;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_work.wait(lk, [&] { return stop || take(c, i); });
+        if (!c) return;
+      }
+      (*c->f)(i);
+      finish(c);
+    }
+  }
+};
+Pool& pool()
+{
+  static Pool p;
+  return p;
+}
+} // namespace
+
+int parallel_width() { return (int)pool().threads.size() + 1; }
+
+void parallel_for(int n, const std::function<void(int)>& f)
+{
+  if (n <= 0) return;
+  if (n == 1) {
+    f(0);
+    return;
+  }
+  Pool& P = pool();
+  Pool::Call call{&f, n};
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.calls.push_back(&call);
+  }
+  P.cv_work.notify_all();
+  for (;;) { // the caller works on its own call
+    int i;
+    {
+      std::lock_guard<std::mutex> lk(P.mu);
+      if (call.next >= call.n) break;
+      i = call.next++;
+    }
+    f(i);
+    P.finish(&call);
+  }
+  std::unique_lock<std::mutex> lk(P.mu);
+  P.cv_done.wait(lk, [&] { return call.done == call.n; });
+  for (auto it = P.calls.begin(); it != P.calls.end(); ++it)
+    if (*it == &call) {
+      P.calls.erase(it);
+      break;
+    }
+}
+} // namespace kr
+
 struct kr_host_lib {
   std::string suffix;
   std::vector<uint64_t> inc;
@@ -1042,10 +1141,9 @@ int kr_format_dist(const kr_host_index* h, const kr_result_view* rv, const char*
 {
   if (!h || !rv || !text || !len) return kr::fail(KR_ERR_ARG, "kr_format_dist: null argument");
   // reads are cut into contiguous ranges, one string per range, joined in order
-  const int nt = rv->nreads >= 4096 ? std::max(1, std::min(omp_get_max_threads(), 16)) : 1;
+  const int nt = std::max(1, std::min(std::min(kr::parallel_width(), 16), (int)(rv->nreads / 4096)));
   std::vector<std::string> part((size_t)nt);
-#pragma omp parallel for num_threads(nt) schedule(static, 1)
-  for (int t = 0; t < nt; ++t) {
+  kr::parallel_for(nt, [&](int t) {
     const uint32_t r0 = (uint32_t)((uint64_t)rv->nreads * t / nt), r1 = (uint32_t)((uint64_t)rv->nreads * (t + 1) / nt);
     std::string& s = part[(size_t)t];
     s.reserve((size_t)(r1 - r0) * 64);
@@ -1070,7 +1168,7 @@ int kr_format_dist(const kr_host_index* h, const kr_result_view* rv, const char*
         s += "\tNA\tNaN\n";
       }
     }
-  }
+  });
   size_t total = 0;
   for (auto& s : part) total += s.size();
   char* p = (char*)malloc(total + 1);

@@ -20,7 +20,8 @@
 #include <cstring>
 #include <map>
 #include <memory>
-#include <omp.h>
+#include <chrono>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -377,10 +378,11 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
   const double* rho_tab = iv.libs[0].rho;
 
   const bool timing = getenv("KR_PLACE_TIMING") != nullptr;
-  double t_mark = omp_get_wtime();
+  auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = wall();
   auto lap = [&](const char* what) {
     if (!timing) return;
-    const double now = omp_get_wtime();
+    const double now = wall();
     fprintf(stderr, "[place] %s %.1f ms\n", what, (now - t_mark) * 1e3);
     t_mark = now;
   };
@@ -394,14 +396,17 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
     uint32_t closest_pt = 0;
   };
   std::vector<ReadPlan> plan(rv->nreads);
-  const int nt = rv->nreads >= 2048 ? std::max(1, std::min(omp_get_max_threads(), 32)) : 1;
+  // one thread per ~4096 reads, at most 32: small batches do not pay for waking a large team
+  const int nt = std::max(1, std::min(std::min(kr::parallel_width(), 32), (int)(rv->nreads / 4096)));
   struct ThreadOut {
     std::vector<Cand> cands;
     std::vector<Acc> closest;
   };
   std::vector<ThreadOut> tout((size_t)nt);
-#pragma omp parallel for num_threads(nt) schedule(static, 1)
-  for (int t = 0; t < nt; ++t) {
+  auto ranged = [&](size_t n, const std::function<void(size_t, size_t)>& body) { // [0, n) in nt contiguous pieces
+    kr::parallel_for(nt, [&](int t) { body(n * (size_t)t / (size_t)nt, n * ((size_t)t + 1) / (size_t)nt); });
+  };
+  kr::parallel_for(nt, [&](int t) {
     ThreadOut& T = tout[(size_t)t];
     const uint32_t ra = (uint32_t)((uint64_t)rv->nreads * t / nt), rb = (uint32_t)((uint64_t)rv->nreads * (t + 1) / nt);
     std::vector<uint32_t> tkey(256), tval(256), tstamp(256, 0);
@@ -503,7 +508,7 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
       }
       pl.c1 = T.cands.size();
     }
-  }
+  });
   lap("A: aggregation");
   // one candidate list in read order: pointers into the threads' vectors
   std::vector<Cand*> cands;
@@ -511,8 +516,7 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
   for (int t = 0; t < nt; ++t) cbase[(size_t)t + 1] = cbase[(size_t)t] + tout[(size_t)t].cands.size(), lbase[(size_t)t + 1] = lbase[(size_t)t] + tout[(size_t)t].closest.size();
   cands.resize(cbase[(size_t)nt]);
   std::vector<const Acc*> closest_acc(lbase[(size_t)nt]);
-#pragma omp parallel for num_threads(nt) schedule(static, 1)
-  for (int t = 0; t < nt; ++t) {
+  kr::parallel_for(nt, [&](int t) {
     const uint32_t ra = (uint32_t)((uint64_t)rv->nreads * t / nt), rb = (uint32_t)((uint64_t)rv->nreads * (t + 1) / nt);
     const size_t cb = cbase[(size_t)t], lb = lbase[(size_t)t];
     for (uint32_t r = ra; r < rb; ++r)
@@ -520,7 +524,7 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
     ThreadOut& T = tout[(size_t)t];
     for (size_t q = 0; q < T.cands.size(); ++q) cands[cb + q] = &T.cands[q];
     for (size_t q = 0; q < T.closest.size(); ++q) closest_acc[lb + q] = &T.closest[q];
-  }
+  });
   lap("A: merge");
   // ---- phase B (GPU): Brent on the internal candidates
   {
@@ -528,16 +532,18 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
     for (size_t i = 0; i < cands.size(); ++i)
       if (cands[i]->internal) which.push_back(i);
     std::vector<double> hist(which.size() * np), uc(which.size()), rho(which.size()), d(which.size()), v(which.size());
-#pragma omp parallel for num_threads(nt) schedule(static)
-    for (size_t j = 0; j < which.size(); ++j) {
+    ranged(which.size(), [&](size_t j0, size_t j1) {
+      for (size_t j = j0; j < j1; ++j) {
       const Acc& a = cands[which[j]]->a;
       for (uint32_t x = 0; x < np; ++x) hist[j * np + x] = a.hist[x];
       uc[j] = a.mismatch, rho[j] = a.rho;
     }
+    });
     int rc = kr_llh_batch(dix, th, 0, which.size(), hist.data(), uc.data(), rho.data(), nullptr, d.data(), v.data());
     if (rc) return rc;
-#pragma omp parallel for num_threads(nt) schedule(static)
-    for (size_t j = 0; j < which.size(); ++j) cands[which[j]]->a.d = d[j], cands[which[j]]->a.v = v[j];
+    ranged(which.size(), [&](size_t j0, size_t j1) {
+      for (size_t j = j0; j < j1; ++j) cands[which[j]]->a.d = d[j], cands[which[j]]->a.v = v[j];
+    });
   }
   lap("B: Brent on internal candidates");
   // ---- phase C (GPU): chisq = 2 * (f_closest(d_candidate) - v_closest)   (src/query.cpp:276, :420-424): one problem per
@@ -550,21 +556,24 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
     std::unique_ptr<double[]> hist(new double[std::max<size_t>(1, nprob * np)]), uc(new double[std::max<size_t>(1, nprob)]),
       rho(new double[std::max<size_t>(1, nprob)]), din(new double[std::max<size_t>(1, nev)]), f(new double[std::max<size_t>(1, nev)]);
     std::unique_ptr<uint32_t[]> pidx(new uint32_t[std::max<size_t>(1, nev)]);
-#pragma omp parallel for num_threads(nt) schedule(static)
-    for (size_t q = 0; q < nprob; ++q) {
+    ranged(nprob, [&](size_t q0, size_t q1) {
+      for (size_t q = q0; q < q1; ++q) {
       const Acc& c = *closest_acc[q];
       for (uint32_t x = 0; x < np; ++x) hist[q * np + x] = c.hist[x];
       uc[q] = c.mismatch, rho[q] = c.rho;
     }
-#pragma omp parallel for num_threads(nt) schedule(static)
-    for (size_t j = 0; j < nev; ++j) pidx[j] = (uint32_t)plan[cands[which[j]]->read].closest, din[j] = cands[which[j]]->a.d;
+    });
+    ranged(nev, [&](size_t j0, size_t j1) {
+      for (size_t j = j0; j < j1; ++j) pidx[j] = (uint32_t)plan[cands[which[j]]->read].closest, din[j] = cands[which[j]]->a.d;
+    });
     int rc = kr_llh_eval_indexed(dix, th, nprob, hist.get(), uc.get(), rho.get(), nev, pidx.get(), din.get(), f.get());
     if (rc) return rc;
-#pragma omp parallel for num_threads(nt) schedule(static)
-    for (size_t j = 0; j < nev; ++j) {
+    ranged(nev, [&](size_t j0, size_t j1) {
+      for (size_t j = j0; j < j1; ++j) {
       Cand& c = *cands[which[j]];
       c.a.chisq = 2 * (f[j] - closest_acc[(size_t)plan[c.read].closest]->v);
     }
+    });
   }
   lap("C: chi-square evaluations");
   // ---- phase D (host, the same read ranges in parallel): candidate filter, LWR, text; pieces joined in order
@@ -599,8 +608,7 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
   const bool jp = tabular == 0, tb = tabular == 1; // 2: --summarize, no text (the caller sums the placements)
   std::vector<std::string> part((size_t)nt);
   std::vector<std::vector<kr_placement>> ppls((size_t)nt);
-#pragma omp parallel for num_threads(nt) schedule(static, 1)
-  for (int t = 0; t < nt; ++t) {
+  kr::parallel_for(nt, [&](int t) {
     const uint32_t ra = (uint32_t)((uint64_t)rv->nreads * t / nt), rb = (uint32_t)((uint64_t)rv->nreads * (t + 1) / nt);
     std::string& out = part[(size_t)t];
     std::vector<kr_placement>& pls = ppls[(size_t)t];
@@ -670,7 +678,7 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
           jfields(out, c.se, c.a), out += "]}";
       }
     }
-  }
+  });
   lap("D: filter + text");
   bool prev = *has_previous != 0;
   size_t total_len = 0, total_pl = 0;

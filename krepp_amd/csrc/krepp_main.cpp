@@ -17,6 +17,7 @@
 #include <cstring>
 #include <ctime>
 #include <deque>
+#include <malloc.h>
 #include <atomic>
 #include <functional>
 #include <map>
@@ -482,6 +483,12 @@ static int run_sketch(const Args& a)
 
 int main(int argc, char** argv)
 {
+  // batches allocate and free tens of MB of rows and text over and over: keep that memory in the heap instead of
+  // mapping and unmapping it each time (page faults and mmap locking showed up as 50 ms stalls per batch)
+  if (!getenv("KR_CLI_DEFAULT_MALLOC")) {
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, -1);
+  }
   fprintf(stderr, "krepp version: " KREPP_VERSION " (krepp-amd, MI355X)\n"); // PRINT_VERSION, src/common.hpp:51
   Args a = parse(argc, argv);
   std::string invocation;

@@ -32,10 +32,10 @@ for extra, env in (([], {}), ([], {"KR_CLI_BATCH_READS": "262144"}), ([], {"KR_C
     print(env, [l for l in r.stderr.strip().splitlines() if "timing" in l or "elapsed" in l])
     dt = time.time() - t
     print(" ".join(extra) or "rows", "rc", r.returncode, "reads", n, "seconds %.2f" % dt, "reads/s %.3g" % (n / dt), "output MB %.1f" % (os.path.getsize(os.path.join(work, "out.tsv")) / 1e6))
-for sub, extra in (("place", []), ("place", ["--tabular"]), ("place", ["--summarize"])):
+for sub, extra, env in (("place", [], {}), ("place", [], {"KR_CLI_DEFAULT_MALLOC": "1"}), ("place", [], {"OMP_WAIT_POLICY": "passive"}), ("place", ["--tabular"], {}), ("place", ["--summarize"], {}), ("dist", [], {})):
     t = time.time()
     r = subprocess.run([exe, sub, "-i", idx, "-q", fq, "-o", os.path.join(work, "out.txt")] + extra, capture_output=True, text=True,
-                       env=dict(os.environ, KR_CLI_TIMING="1"))
+                       env=dict(os.environ, KR_CLI_TIMING="1", **env))
     dt = time.time() - t
-    print(sub, extra, [l for l in r.stderr.strip().splitlines() if "timing" in l or "elapsed" in l])
+    print(sub, extra, env, [l for l in r.stderr.strip().splitlines() if "timing" in l or "elapsed" in l])
     print(sub, " ".join(extra), "rc", r.returncode, "reads", n, "seconds %.2f" % dt, "reads/s %.3g" % (n / dt), "output MB %.1f" % (os.path.getsize(os.path.join(work, "out.txt")) / 1e6))
