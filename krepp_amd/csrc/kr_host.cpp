@@ -805,21 +805,22 @@ struct FqPool {
   }
   void parse(FqChunk& c)
   {
-    std::vector<unsigned char> buf((size_t)(c.b - c.a));
+    const size_t len = (size_t)(c.b - c.a);
+    std::unique_ptr<unsigned char[]> buf(new unsigned char[std::max<size_t>(1, len)]); // not zero-filled
     size_t p = 0;
-    if (pread_all(fd, buf.data(), c.a, buf.size())) {
-      c.bases.reserve(buf.size() / 2);
+    if (pread_all(fd, buf.get(), c.a, len)) {
+      c.bases.reserve(len / 2);
       size_t nb, ne, s0, slen, next;
-      while (p < buf.size() && clean_record(buf.data(), p, buf.size(), 0, nb, ne, s0, slen, next) == Clean::Ok) {
+      while (p < len && clean_record(buf.get(), p, len, 0, nb, ne, s0, slen, next) == Clean::Ok) {
         c.name_off.push_back(c.name_blob.size());
-        c.name_blob.append((const char*)buf.data() + nb, ne - nb);
+        c.name_blob.append((const char*)buf.get() + nb, ne - nb);
         c.name_blob.push_back('\0');
-        c.bases.insert(c.bases.end(), buf.data() + s0, buf.data() + s0 + slen);
+        c.bases.insert(c.bases.end(), buf.get() + s0, buf.get() + s0 + slen);
         c.offsets.push_back(c.bases.size());
         p = next;
       }
     }
-    c.ok = p == buf.size() && !buf.empty();
+    c.ok = p == len && len != 0;
     c.clean_end = c.a + p;
   }
   void work()
