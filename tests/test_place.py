@@ -244,3 +244,69 @@ def test_cli_place_lineages_and_summarize(po, toy_index_dir, toy_reads, tmp_path
     assert r.returncode == 0, r.stderr
     inv = f"{exe} place -i {toy_index_dir} -q {fq} --summarize"
     assert r.stdout == ox.place_frame(0, 2, inv) + ox.place_summarize(bases, offs, po.params(no_filter=0))
+
+
+@pytest.mark.gpu
+def test_large_batch_goes_through_the_thread_pool(capi, po, toy_index_dir, toy_reads):
+    """Batches of more than 8,192 reads are cut into ranges handled by several host threads (kr::parallel_for):
+    aggregation, candidate lists, text pieces and the jplace separators must come out as for one thread."""
+    names, bases, offs = toy_reads
+    reps = 70
+    n1 = len(names)
+    big_names = [f"{nm}_{r}" for r in range(reps) for nm in names]
+    big_bases = np.tile(bases, reps)
+    lens = np.diff(offs)
+    big_offs = np.concatenate([[0], np.cumsum(np.tile(lens, reps))]).astype(np.uint64)
+    assert len(big_names) == n1 * reps > 20000
+    hx = capi.HostIndex(toy_index_dir)
+    ox = po.Index(toy_index_dir)
+    ox.set_placement_tree(None)
+    for tabular in (0, 1, 2):
+        placer = capi.Placer(hx, None, 0, tabular=tabular, max_reads=len(big_names), max_bases=len(big_bases))
+        text, pl = placer.place(big_bases, big_offs, big_names)
+        if tabular == 2:
+            assert placer.summary() == ox.place_summarize(big_bases, big_offs, po.params(no_filter=0, num_threads=8))
+        else:
+            want = ox.place(big_bases, big_offs, big_names, po.params(no_filter=0, num_threads=8), tabular=bool(tabular))
+            assert text == want["text"]
+            assert placements_key(pl) == placements_key(want["placements"])
+        placer.close()
+    # dist rows through the same pool
+    dx = hx.upload(0)
+    st = dx.stream(max_reads=len(big_names), max_bases=len(big_bases), max_records=len(big_names) * 32)
+    st.submit(big_bases, big_offs)
+    st.collect()
+    assert st.format_dist(hx, big_names) == ox.dist(big_bases, big_offs, big_names, po.params(collect=4, num_threads=8))["text"]
+
+
+@pytest.mark.gpu
+def test_cli_dist_on_a_file_large_enough_for_the_parallel_reader(po, toy_index_dir, toy_reads, tmp_path):
+    """> 32 MB of plain FASTQ: the default configuration parses it in chunks on the thread pool, runs several
+    65,536-read batches on two workers and writes them in input order."""
+    import subprocess
+    from conftest import ROOT
+    names, bases, offs = toy_reads
+    reps = 440
+    fq = tmp_path / "big.fq"
+    recs = []
+    for i, nm in enumerate(names):
+        t = bytes(bases[int(offs[i]):int(offs[i + 1])])
+        recs.append((nm.encode(), t))
+    with open(fq, "wb") as f:
+        for r in range(reps):
+            f.write(b"".join(b"@%s_%d some comment\n%s\n+\n%s\n" % (nm, r, t, b"I" * len(t)) for nm, t in recs))
+    assert os.path.getsize(fq) > (32 << 20)
+    exe = os.path.join(ROOT, "krepp_amd", "lib", "krepp")
+    r = subprocess.run([exe, "dist", "-i", toy_index_dir, "-q", str(fq)], capture_output=True, text=True,
+                       env=dict(os.environ, KR_CLI_TIMING="1"))
+    assert r.returncode == 0, r.stderr
+    ox = po.Index(toy_index_dir)
+    one = ox.dist(bases, offs, names, po.params(collect=4))["text"].splitlines()
+    got = r.stdout.splitlines()[2:]
+    assert len(got) == len(one) * reps
+    # every repetition is the toy batch with renamed reads
+    for rep in (0, 1, reps // 2, reps - 1):
+        chunk = got[rep * len(one):(rep + 1) * len(one)]
+        want = [l.split("\t", 1)[0] + f"_{rep}\t" + l.split("\t", 1)[1] for l in one]
+        assert chunk == want, rep
+    assert len(set(l.split("\t", 1)[0] for l in got)) == len(names) * reps
