@@ -24,15 +24,10 @@ with open(fq, "wb") as f:
         f.write(b"".join(rows))
         done += m
 exe = os.path.join(root, "krepp_amd", "lib", "krepp")
-for extra, env in (([], {}), ([], {"KR_CLI_BATCH_READS": "262144"}), ([], {"KR_CLI_BATCH_READS": "262144", "KR_CLI_WORKERS_PER_GPU": "1"}),
-                   ([], {"KR_FASTX_THREADS": "0", "KR_CLI_WORKERS_PER_GPU": "1"}), (["--summarize"], {})):
-    t = time.time()
-    r = subprocess.run([exe, "dist", "-i", idx, "-q", fq, "-o", os.path.join(work, "out.tsv")] + extra, capture_output=True, text=True,
-                       env=dict(os.environ, KR_CLI_TIMING="1", **env))
-    print(env, [l for l in r.stderr.strip().splitlines() if "timing" in l or "elapsed" in l])
-    dt = time.time() - t
-    print(" ".join(extra) or "rows", "rc", r.returncode, "reads", n, "seconds %.2f" % dt, "reads/s %.3g" % (n / dt), "output MB %.1f" % (os.path.getsize(os.path.join(work, "out.tsv")) / 1e6))
-for sub, extra, env in (("place", [], {}), ("place", [], {"KR_CLI_DEFAULT_MALLOC": "1"}), ("place", [], {"OMP_WAIT_POLICY": "passive"}), ("place", ["--tabular"], {}), ("place", ["--summarize"], {}), ("dist", [], {})):
+for sub, extra, env in (("dist", [], {}), ("dist", [], {"KR_CLI_BATCH_READS": "131072"}), ("dist", [], {"KR_CLI_BATCH_READS": "262144"}),
+                        ("dist", [], {"KR_CLI_WORKERS_PER_GPU": "3"}), ("dist", ["--summarize"], {}),
+                        ("place", [], {}), ("place", [], {"KR_CLI_BATCH_READS": "131072"}), ("place", [], {"KR_CLI_WORKERS_PER_GPU": "3"}),
+                        ("place", ["--tabular"], {}), ("place", ["--summarize"], {})):
     t = time.time()
     r = subprocess.run([exe, sub, "-i", idx, "-q", fq, "-o", os.path.join(work, "out.txt")] + extra, capture_output=True, text=True,
                        env=dict(os.environ, KR_CLI_TIMING="1", **env))
