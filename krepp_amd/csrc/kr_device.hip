@@ -2707,7 +2707,8 @@ int kr_index_upload(const kr_index_view* v, int device, uint32_t flags, kr_index
     }
   }
   H.nleaves = (uint32_t)leaf_se.size();
-  if (2ull * H.nleaves > 65536) return kr::fail(KR_ERR_ARG, "kr_index_upload: more than 32768 reference leaves is not supported");
+  // 2 key bits per leaf in the accumulate kernel's LDS bitmaps: 65,536 leaves = 45 KB of the 64 KB a workgroup may use
+  if (2ull * H.nleaves > 131072) return kr::fail(KR_ERR_ARG, "kr_index_upload: more than 65536 reference leaves is not supported");
   { // lanes per probe: a bucket of L entries spans about (L + 4.5) / 4 aligned 16-byte chunks
     double nk = 0, nr = 0;
     for (uint32_t i = 0; i < v->nlibs; ++i) nk += (double)v->libs[i].nkmers, nr += (double)v->libs[i].nrows;
@@ -2945,6 +2946,8 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   const uint32_t nslots2 = std::max<uint32_t>(2u, 2u * ix->dix.nleaves), bm_words = ((nslots2 + 63) / 64) * 2;
   // resident accumulate waves per CU: LDS-limited, at most 16 by registers (4 per SIMD); reads are handed out
   // dynamically, so a grid that is not fully resident costs nothing
+  if (probe_lds_bytes(p->hdist_th + 1, bm_words) > 65536u)
+    return kr::fail(KR_ERR_ARG, "kr_stream_create: this many reference leaves with this --hdist-th needs more LDS than a workgroup has");
   uint32_t per_cu = std::min<uint32_t>(16u, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words));
   // the single-segment instantiation has a lean LDS layout and 96 registers: 5 waves per SIMD
   uint32_t per_cu_lean = std::min<uint32_t>(20u, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words, true));
@@ -2954,6 +2957,15 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   }
   s->nwaves_full = (uint32_t)prop.multiProcessorCount * std::max<uint32_t>(1u, per_cu);
   s->nwaves_lean = (uint32_t)prop.multiProcessorCount * std::max<uint32_t>(1u, per_cu_lean);
+  { // per-wave global scratch grows with the tree (100 B per leaf for the level-2 tables): bound the total by running
+    // fewer waves on very large trees (reads are handed out dynamically, so any grid size is correct)
+    const uint64_t np_ = p->hdist_th + 1;
+    const uint64_t per_wave = (uint64_t)nslots2 * np_ * (kPlaneWords + 1) * 4 + (uint64_t)std::max<uint32_t>(nslots2, kEvSpill + 8192u) * 4;
+    const uint64_t budget = (getenv("KR_ACC_SCRATCH_GB") ? (uint64_t)atoi(getenv("KR_ACC_SCRATCH_GB")) : 16ull) << 30;
+    const uint32_t max_waves = (uint32_t)std::max<uint64_t>((uint64_t)prop.multiProcessorCount, budget / per_wave);
+    s->nwaves_full = std::min(s->nwaves_full, max_waves);
+    s->nwaves_lean = std::min(s->nwaves_lean, max_waves);
+  }
   s->nwaves = std::max(s->nwaves_full, s->nwaves_lean);
   // default record capacity: up to 2 * leaves per read, at most 16 per read on average
   uint64_t per_read = std::min<uint64_t>(16, std::max<uint64_t>(8, (uint64_t)ix->dix.tree_nnodes + 1));
@@ -3014,8 +3026,11 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   SA(o.g_planes, (uint64_t)s->nwaves * nslots2 * np * kPlaneWords);
   SA(o.g_counts, (uint64_t)s->nwaves * nslots2 * np);
   SA(o.g_list, (uint64_t)s->nwaves * g_list_words);
-  HIP_TRY(hipMemset(o.g_planes, 0, (uint64_t)s->nwaves * nslots2 * np * kPlaneWords * 4));
-  HIP_TRY(hipMemset(o.g_counts, 0, (uint64_t)s->nwaves * nslots2 * np * 4));
+  // on the stream's own stream and waited for: the stream does not synchronise with the null stream, and a
+  // multi-GB clear (large trees) would otherwise still be running when the first batch arrives
+  HIP_TRY(hipMemsetAsync(o.g_planes, 0, (uint64_t)s->nwaves * nslots2 * np * kPlaneWords * 4, s->stream));
+  HIP_TRY(hipMemsetAsync(o.g_counts, 0, (uint64_t)s->nwaves * nslots2 * np * 4, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
   HA(s->h_bases, max_bases + 256);
   HA(s->h_offsets, (uint64_t)max_reads + 1);
   HA(s->h_counters, 32);

@@ -312,6 +312,42 @@ def test_many_leaves_bitmap_spans_several_tiles(capi, po, synth, tmp_path):
         assert_rows_close(res.rows(), rows_of_oracle(ref))
 
 
+def test_forty_thousand_leaves(capi, po, synth, tmp_path):
+    """40,000 references (the reference's larger public indexes have 16-50 thousand): 80,000 key bits = 10 KB of LDS
+    bitmap per wave, fewer resident accumulate waves, per-wave scratch bounded by running fewer waves."""
+    n = 40000
+    nwk = synth.yule_newick(n, 5)
+    g = synth.evolve_genomes(nwk, 400, seed=31)
+    tsv = synth.write_genomes(g, str(tmp_path / "g"))
+    (tmp_path / "t.nwk").write_text(nwk)
+    idx = str(tmp_path / "ix")
+    capi.build_index(tsv, idx, nwk=str(tmp_path / "t.nwk"), k=29, w=33, h=13, m=2, r=0, frac=True, num_threads=8)
+    hx = capi.HostIndex(idx)
+    dx = hx.upload(0)
+    ox = po.Index(idx)
+    for length, seed in ((150, 3), (300, 4)):
+        bases, offs, rn = synth.sample_reads(g, 600, seed=seed, length=length)
+        ref = ox.dist(bases, offs, rn, po.params(collect=7, num_threads=8))
+        acc = ref["accs"][ref["accs"]["passed"] == 1]
+        want = sorted(zip(acc["read"].tolist(), ((acc["se"] << 1) | acc["strand"]).tolist(), [tuple(x[:5]) for x in acc["hist"].tolist()]))
+        # default path, then the plane-table fallbacks forced (their per-wave tables are GBs at this tree size:
+        # the very first batch of a fresh stream must already see them cleared)
+        for dbg in ("0", "8", "8192"):
+            os.environ["KR_DEBUG_SKIP"] = dbg
+            try:
+                st = dx.stream(max_reads=600, max_bases=len(bases), max_records=600 * 2048)
+                st.submit(bases, offs, capi.KR_TAP_ACCS)
+                res = st.collect()
+            finally:
+                del os.environ["KR_DEBUG_SKIP"]
+            got = sorted(zip(res.rec_read.tolist(), res.rec_key.tolist(), [tuple(x) for x in res.rec_hist.tolist()]))
+            assert got == want and len(got) > 2000, (length, dbg)
+            assert_rows_close(res.rows(), rows_of_oracle(ref))
+            st.close()
+    # one leaf too many for the LDS bitmaps is refused at upload, not mis-handled
+    assert hx.view.tree_nnodes < 2 * 65536
+
+
 def test_device_brent_vs_oracle(capi, po, toy):
     hx, dx, ox = toy
     rng = np.random.default_rng(31)
