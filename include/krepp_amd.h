@@ -243,6 +243,7 @@ typedef struct kr_timing {
   float ms_llh;      /* likelihood + selection kernels                               */
   float ms_h2d;      /* host->device copies (0 with KR_BASES_DEVICE)                 */
   uint32_t overflow_reads; /* reads that took the global-memory accumulator path     */
+  uint32_t stack_spills;   /* times a colour-expansion stack outgrew the LDS (large clades) */
 } kr_timing;
 KR_API int kr_batch_timing(kr_stream*, kr_timing* out);
 

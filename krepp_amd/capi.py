@@ -62,7 +62,7 @@ class KrHit(C.Structure):
 
 class KrTiming(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_scan", C.c_float), ("ms_acc", C.c_float), ("ms_llh", C.c_float),
-                ("ms_h2d", C.c_float), ("overflow_reads", C.c_uint32)]
+                ("ms_h2d", C.c_float), ("overflow_reads", C.c_uint32), ("stack_spills", C.c_uint32)]
 
 
 class KrFastxBatch(C.Structure):

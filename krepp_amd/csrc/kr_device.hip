@@ -147,6 +147,7 @@ struct BatchOut {
   uint32_t* g_planes; // [nwaves][nslots2][np][4]
   uint32_t* g_counts; // [nwaves][nslots2][np]
   uint32_t* g_list;   // [nwaves][nslots2]
+  uint64_t* stk_spill; // [nwaves][kStackSpill] lower part of a work stack that outgrew the LDS (large clades)
   uint32_t nslots2;   // 2 * nleaves
   uint32_t g_list_words; // per wave: max(nslots2, ev_spill + tab_spill * (hist words + 1))
   uint32_t ev_spill, tab_spill, kt_spill; // event-mode spill capacities per wave (events, table entries, keys)
@@ -325,11 +326,14 @@ struct WaveState {
   lds_u64* stack;   // LDS [stack_cap]: lo | hi << 32
   uint32_t stack_cap; // entries (wave-uniform)
   uint32_t top;   // wave-uniform
+  uint64_t* gstk; // global spill of the stack's oldest entries (wave-private)
+  uint32_t gs_top; // entries spilled (wave-uniform)
   bool l2;        // this lane sent something to level 2 during this read
   uint32_t err;
   uint32_t rec_next, rec_end; // wave-private range of record slots (wave-uniform)
   uint32_t n_l2;              // reads of this wave that used level 2
   uint32_t n_rec;             // records this wave emitted
+  uint32_t n_spill;           // times the work stack moved its older half to global memory
   uint32_t ll_next, ll_end;   // wave-private chunk of out.long_list (wave-uniform)
   // event mode (reads of a single segment): leaf updates are appended as 32-bit events
   bool evmode;      // wave-uniform
@@ -451,16 +455,57 @@ __device__ __forceinline__ void expand_step(const DevIndex& ix, const Acc& A, Wa
 }
 
 // drain the work stack
+// The LDS stack is the top of a two-level stack.  A colour that covers a large clade fans out faster than it is
+// consumed (64 items popped, up to 128 pushed): when no room is left the OLDER half moves to the wave's global spill
+// (LIFO never needs it before the newer half is gone), and it comes back when the LDS part has run empty.
+constexpr uint32_t kStackSpill = 8192; // entries per wave (64 KiB)
+// (by value: a WaveState passed by reference to a real call would have to live in scratch memory)
+__device__ __noinline__ uint32_t stack_spill(lds_u64* stack, uint64_t* gstk, uint32_t top, uint32_t gs_top)
+{ // returns the number of entries moved out (0: the spill is full)
+  const uint32_t lane = lane_id(), half = top / 2u;
+  if (half == 0 || gs_top + half > kStackSpill) return 0;
+  for (uint32_t i = lane; i < half; i += 64) gstk[gs_top + i] = stack[i];
+  WAVE_SYNC();
+  for (uint32_t i0 = 0; i0 < top - half; i0 += 64) { // move the newer part down, tile by tile (ascending: no overlap hazard)
+    const uint32_t i = i0 + lane;
+    uint64_t v = 0;
+    if (i < top - half) v = stack[half + i];
+    WAVE_SYNC();
+    if (i < top - half) stack[i] = v;
+    WAVE_SYNC();
+  }
+  return half;
+}
+__device__ __noinline__ uint32_t stack_refill(lds_u64* stack, const uint64_t* gstk, uint32_t cap, uint32_t gs_top)
+{ // returns the number of entries brought back
+  const uint32_t lane = lane_id(), m = min(gs_top, cap / 2u);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // this wave's earlier spill stores have landed
+  for (uint32_t i = lane; i < m; i += 64) stack[i] = gstk[gs_top - m + i];
+  WAVE_SYNC();
+  return m;
+}
+
 template <bool SL>
 __device__ __forceinline__ void expand_all(const DevIndex& ix, const Acc& A, WaveState& ws)
 {
   const uint32_t lane = lane_id();
-  while (ws.top > 0) {
+  for (;;) {
+    if (ws.top == 0) {
+      if (ws.gs_top == 0) break;
+      const uint32_t m = stack_refill(ws.stack, ws.gstk, ws.stack_cap, ws.gs_top);
+      ws.gs_top -= m, ws.top = m;
+    }
     const uint32_t room = ws.stack_cap - ws.top;
     const uint32_t n = min(min(64u, ws.top), room);
-    if (n == 0) { // cannot make progress: report, drop the rest
-      ws.err |= kErrStack;
-      ws.top = 0;
+    if (n == 0) { // no room for the children of even one item
+      const uint32_t half = stack_spill(ws.stack, ws.gstk, ws.top, ws.gs_top);
+      if (half) {
+        ws.gs_top += half, ws.top -= half;
+        ws.n_spill++;
+        continue;
+      }
+      ws.err |= kErrStack; // the spill is full too: report, drop the rest
+      ws.top = 0, ws.gs_top = 0;
       break;
     }
     const uint32_t base = ws.top - n;
@@ -1704,12 +1749,15 @@ __global__ __launch_bounds__(kWave, (MULTI ? 4 : 5)) void kr_acc_kernel_t(DevInd
   ws.stack_cap = stack_bytes / 8u;
   ws.lean = !MULTI;
   ws.top = 0;
+  ws.gstk = out.stk_spill + w * (uint64_t)kStackSpill;
+  ws.gs_top = 0;
   ws.l2 = false;
   ws.err = 0;
   ws.rec_next = 0;
   ws.rec_end = 0;
   ws.n_l2 = 0;
   ws.n_rec = 0;
+  ws.n_spill = 0;
   ws.ll_next = ws.ll_end = 0;
   ws.evmode = false;
   ws.nev = 0;
@@ -1736,6 +1784,7 @@ __global__ __launch_bounds__(kWave, (MULTI ? 4 : 5)) void kr_acc_kernel_t(DevInd
   for (uint32_t q = ws.ll_next + lane_id(); q < ws.ll_end; q += 64) out.long_list[q] = 0xFFFFFFFFu;
   if (ws.n_l2 && lane_id() == 0) atomicAdd(&out.counters[2], ws.n_l2);
   if (ws.n_rec && lane_id() == 0) atomicAdd(&out.counters[4], ws.n_rec);
+  if (ws.n_spill && lane_id() == 0) atomicAdd(&out.counters[26], ws.n_spill);
 }
 
 // ---------------------------------------------------------------------------
@@ -2912,7 +2961,7 @@ uint32_t next_pow2(uint32_t v)
 int check_errflags(uint32_t e)
 {
   if (e & kErrRecCap) return kr::fail(KR_ERR_CAPACITY, "record buffer overflow: submit fewer reads per batch");
-  if (e & kErrStack) return kr::fail(KR_ERR_CAPACITY, "colour work stack overflow (colour DAG deeper than supported)");
+  if (e & kErrStack) return kr::fail(KR_ERR_CAPACITY, "colour work stack overflow (a colour expands into more pending work than the LDS stack and its spill hold)");
   if (e & kErrTable) return kr::fail(KR_ERR_CAPACITY, "global accumulator table overflow");
   if (e & kErrHitCap) return kr::fail(KR_ERR_CAPACITY, "hit tap buffer overflow");
   if (e & kErrItemCap) return kr::fail(KR_ERR_CAPACITY, "hit list overflow (more than 256 table hits per read on average): submit fewer reads per batch");
@@ -3016,6 +3065,7 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   SA(o.rd_it_off, max_reads);
   SA(o.rd_it_cnt, max_reads);
   SA(o.long_list, (uint64_t)max_reads + 16ull * s->nwaves);
+  SA(o.stk_spill, (uint64_t)s->nwaves * kStackSpill);
   o.nslots2 = nslots2;
   o.ev_spill = kEvSpill;
   o.tab_spill = std::min<uint32_t>(nslots2, 4096u);
@@ -3304,6 +3354,7 @@ int kr_batch_timing(kr_stream* s, kr_timing* t)
   HIP_TRY(hipEventElapsedTime(&t->ms_llh, s->ev[3], s->ev[4]));
   HIP_TRY(hipEventElapsedTime(&t->ms_total, s->ev[1], s->ev[4]));
   t->overflow_reads = s->h_counters[2];
+  t->stack_spills = s->h_counters[26];
   return KR_OK;
 }
 

@@ -348,6 +348,34 @@ def test_forty_thousand_leaves(capi, po, synth, tmp_path):
     assert hx.view.tree_nnodes < 2 * 65536
 
 
+def test_large_clade_colours_spill_the_work_stack(capi, po, synth, tmp_path):
+    """3,000 nearly identical genomes: almost every k-mer carries the colour of a clade of hundreds to thousands of
+    leaves.  Expanding such a colour fans out faster than the 64-wide pops consume it; the work stack (192 / 256
+    entries of LDS) moves its older half to global memory instead of giving up (before: KR_ERR_CAPACITY)."""
+    n = 3000
+    nwk = synth.yule_newick(n, 9, mean_blen=0.0003)
+    g = synth.evolve_genomes(nwk, 500, seed=5)
+    tsv = synth.write_genomes(g, str(tmp_path / "g"))
+    (tmp_path / "t.nwk").write_text(nwk)
+    idx = str(tmp_path / "ix")
+    capi.build_index(tsv, idx, nwk=str(tmp_path / "t.nwk"), k=29, w=33, h=13, m=2, r=0, frac=True, num_threads=8)
+    hx = capi.HostIndex(idx)
+    dx = hx.upload(0)
+    ox = po.Index(idx)
+    bases, offs, rn = synth.sample_reads(g, 120, seed=3, length=150)
+    ref = ox.dist(bases, offs, rn, po.params(collect=7, num_threads=8))
+    acc = ref["accs"][ref["accs"]["passed"] == 1]
+    want = sorted(zip(acc["read"].tolist(), ((acc["se"] << 1) | acc["strand"]).tolist(), [tuple(x[:5]) for x in acc["hist"].tolist()]))
+    assert len(want) > 100 * 1000  # most reads reach most of the tree
+    st = dx.stream(max_reads=120, max_bases=len(bases), max_records=120 * 2 * n + 4096)
+    st.submit(bases, offs, capi.KR_TAP_ACCS)
+    res = st.collect()
+    got = sorted(zip(res.rec_read.tolist(), res.rec_key.tolist(), [tuple(x) for x in res.rec_hist.tolist()]))
+    assert got == want
+    assert_rows_close(res.rows(), rows_of_oracle(ref))
+    assert st.timing().stack_spills > 0
+
+
 def test_device_brent_vs_oracle(capi, po, toy):
     hx, dx, ox = toy
     rng = np.random.default_rng(31)
