@@ -376,6 +376,34 @@ def test_large_clade_colours_spill_the_work_stack(capi, po, synth, tmp_path):
     assert st.timing().stack_spills > 0
 
 
+@pytest.mark.parametrize("cfg", [(19, 24, 3, 1, 0, True), (21, 21, 7, 2, 1, False), (24, 31, 8, 3, 1, True), (26, 32, 10, 4, 3, True),
+                                 (29, 35, 13, 4, 0, False), (30, 33, 14, 7, 2, True), (31, 38, 15, 4, 1, True)])
+def test_configuration_sweep(capi, po, synth, tmp_path, cfg):
+    """k, w, h, m, r, frac x hdist_th x read length: index built by the CPU builder, rows byte-identical to the oracle's
+    (scripts/sweep_configs.py runs the full grid: 42 index configurations x 5 query settings)."""
+    k, w, h, m, r, frac = cfg
+    nwk = "((a:0.02,b:0.02):0.02,(c:0.03,(d:0.01,e:0.01):0.02):0.01,(f:0.05,g:0.002):0.01);"
+    g = synth.evolve_genomes(nwk, 20000, seed=9)
+    tsv = synth.write_genomes(g, str(tmp_path / "g"))
+    (tmp_path / "t.nwk").write_text(nwk)
+    idx = str(tmp_path / "ix")
+    capi.build_index(tsv, idx, nwk=str(tmp_path / "t.nwk"), k=k, w=w, h=h, m=m, r=r, frac=frac, num_threads=8, seed=k)
+    hx = capi.HostIndex(idx)
+    dx = hx.upload(0)
+    ox = po.Index(idx)
+    for th, L, nreads in ((4, 150, 200), (0, 90, 200), (6, 151, 200), (9, 260, 100)):
+        if h == 3:
+            nreads = 20  # 64 LSH rows: thousands of table hits per read
+        bases, offs, _ = synth.sample_reads(g, nreads, seed=th + L, length=L)
+        rn = [f"r{i}" for i in range(nreads)]
+        ref = ox.dist(bases, offs, rn, po.params(hdist_th=th, collect=4, num_threads=8))
+        st = dx.stream(params=capi.default_params(hdist_th=th), max_reads=nreads, max_bases=len(bases), max_records=nreads * 64)
+        st.submit(bases, offs)
+        st.collect()
+        assert st.format_dist(hx, rn) == ref["text"], (cfg, th, L)
+        st.close()
+
+
 def test_device_brent_vs_oracle(capi, po, toy):
     hx, dx, ox = toy
     rng = np.random.default_rng(31)
