@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, assert_rows_close, rows_of_oracle
+from conftest import GOLDEN, ROOT, assert_rows_close, rows_of_oracle
 from helpers import closed_form, hd32, revcomp, row_of, write_index
 
 pytestmark = pytest.mark.gpu
@@ -560,3 +560,37 @@ def test_cli_dist_summarize(po, toy_index_dir, toy_reads):
     for g, w in zip(gw, ww):
         assert abs(float(g[1]) - float(w[1])) <= 2e-5 and abs(float(g[2]) - float(w[2])) <= 2e-5
     assert abs(sum(float(g[2]) for g in gw) - 1.0) < 1e-3
+
+
+def test_cli_contig_queries_multiline_fasta(po, synth, tmp_path):
+    """Queries need not be reads: whole contigs (200 kb, wrapped FASTA lines) go through the same path -- thousands of
+    segments per sequence in the accumulate kernel's merged mode -- and give the oracle's rows."""
+    import subprocess
+    nwk_path = os.path.join(GOLDEN, "tree_toy.nwk")
+    g = synth.evolve_genomes(open(nwk_path).read(), 200_000, seed=7)
+    tsv = synth.write_genomes(g, str(tmp_path / "g"))
+    idx = str(tmp_path / "idx")
+    from krepp_amd import capi
+    capi.build_index(tsv, idx, nwk=nwk_path, k=27, w=35, h=11, m=4, r=1, frac=True, num_threads=8)
+    rng = np.random.default_rng(3)
+    names, seqs = [], []
+    for nm, s in list(g.items())[:6]:
+        s = s.copy()
+        mut = rng.random(len(s)) < 0.02
+        s[mut] = rng.choice(np.frombuffer(b"ACGT", np.uint8), int(mut.sum()))
+        for j, (a, b) in enumerate(((0, 200_000), (10_000, 70_000), (500, 3_500))):
+            names.append(f"{nm}_c{j}")
+            seqs.append(s[a:b].tobytes())
+    fa = tmp_path / "q.fa"
+    with open(fa, "wb") as f:
+        for nm, s in zip(names, seqs):
+            f.write(b">" + nm.encode() + b" description\n")
+            for o in range(0, len(s), 80):
+                f.write(s[o:o + 80] + b"\n")
+    exe = os.path.join(ROOT, "krepp_amd", "lib", "krepp")
+    r = subprocess.run([exe, "dist", "-i", idx, "-q", str(fa)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    bases = np.frombuffer(b"".join(seqs), np.uint8)
+    offs = np.cumsum([0] + [len(s) for s in seqs]).astype(np.uint64)
+    ref = po.Index(idx).dist(bases, offs, names, po.params(collect=4, num_threads=8))
+    assert r.stdout.split("\n", 2)[2] == ref["text"] and ref["text"].count("\n") > 50
