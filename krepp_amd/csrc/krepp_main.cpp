@@ -211,6 +211,11 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
       cv_done.notify_all();
       return;
     }
+    // reads per submit this worker currently trusts: halved when a submit overflows a device buffer, doubled again
+    // after a run of successes -- data with hundreds of rows per read settle at a piece size instead of failing a
+    // full-size submit (and every intermediate size) for every batch
+    size_t piece = SIZE_MAX;
+    int streak = 0;
     for (;;) {
       Job* j = nullptr;
       {
@@ -228,6 +233,11 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
       // reads [lo, hi) of the job; a batch that overflows a device-side buffer (KR_ERR_CAPACITY: unusually many
       // table hits or records per read) is resubmitted in halves, as include/krepp_amd.h prescribes
       std::function<int(size_t, size_t)> run = [&](size_t lo, size_t hi) -> int {
+        if (hi - lo > piece && hi - lo > 1) { // known to be too much for one submit
+          const size_t mid = lo + (hi - lo) / 2;
+          const int rc0 = run(lo, mid);
+          return rc0 ? rc0 : run(mid, hi);
+        }
         std::vector<uint64_t> offs(hi - lo + 1);
         for (size_t i = lo; i <= hi; ++i) offs[i - lo] = j->offsets[i] - j->offsets[lo];
         kr_result_view rv;
@@ -240,6 +250,8 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
         ns_dev += since(t_dev);
         auto t_fmt = now();
         if (rc == KR_ERR_CAPACITY && hi - lo > 1) {
+          piece = std::min(piece, (hi - lo + 1) / 2);
+          streak = 0;
           const size_t mid = lo + (hi - lo) / 2;
           rc = run(lo, mid);
           return rc ? rc : run(mid, hi);
@@ -270,6 +282,7 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
         if (!rc && txt) text.append(txt, len);
         kr_free(txt);
         ns_fmt += since(t_fmt);
+        if (!rc && piece != SIZE_MAX && ++streak >= 16) piece = piece > SIZE_MAX / 2 ? SIZE_MAX : piece * 2, streak = 0;
         return rc;
       };
       const int rc = run(0, j->names.size());

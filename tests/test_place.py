@@ -310,3 +310,9 @@ def test_cli_dist_on_a_file_large_enough_for_the_parallel_reader(po, toy_index_d
         want = [l.split("\t", 1)[0] + f"_{rep}\t" + l.split("\t", 1)[1] for l in one]
         assert chunk == want, rep
     assert len(set(l.split("\t", 1)[0] for l in got)) == len(names) * reps
+    # device buffers far too small for a 65,536-read submit: the workers settle at a smaller piece size after the
+    # first overflow instead of failing every full-size submit again; same output
+    r2 = subprocess.run([exe, "dist", "-i", toy_index_dir, "-q", str(fq)], capture_output=True, text=True,
+                        env=dict(os.environ, KR_DEBUG_CLI_RECORDS="20000"))
+    assert r2.returncode == 0, r2.stderr
+    assert r2.stdout.splitlines()[2:] == got
