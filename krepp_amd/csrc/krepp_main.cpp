@@ -52,13 +52,62 @@ static const std::map<std::string, std::string> kAlias = {
 };
 static const char* kFlags[] = {"--multi", "--filter", "--summarize", "--frac", "--verbose", "--gpu-minimizers", "--tabular"};
 
+// options as in the reference's CLI (src/krepp.cpp:516-675); the texts are this build's own
+static void print_help(const std::string& sub)
+{
+  const char* query_opts =
+    "  -q, --query PATH           query FASTA/FASTQ file (gzip accepted)\n"
+    "  -o, --output-path PATH     write the report here [stdout]\n"
+    "      --hdist-th N           largest Hamming distance at which a k-mer matches [4]\n";
+  const char* index_query_opts =
+    "  -i, --index-dir DIR        index directory (as written by `krepp index`, this build's or the reference's)\n"
+    "      --chisq X              chi-square threshold of the likelihood-ratio filter [2.706]\n"
+    "      --dist-max X           report only distances below X (1e-8 .. 0.33)\n"
+    "      --multi / --no-multi   report every reference / edge that passes, or only the best [multi]\n"
+    "      --summarize            weighted read counts per reference / edge instead of per-read rows\n"
+    "      --gpus N, --device D   GPUs to use (index replicated on each), first device [1, 0]\n";
+  const char* build_opts =
+    "  -k, --kmer-len N           k-mer length, 19..31\n"
+    "  -w, --win-len N            minimizer window (>= k) [k+6]\n"
+    "  -h, --num-positions N      LSH positions [k-16]\n"
+    "  -m, --modulo-lsh N         modulo partitioning the LSH space [4]\n"
+    "  -r, --residue-lsh N        keep k-mers with LSH(x) mod m == r [1]\n"
+    "      --frac / --no-frac     keep k-mers with LSH(x) mod m <= r [frac]\n"
+    "      --seed N               seed of the random LSH positions\n";
+  printf("krepp (MI355X build, mirrors krepp v0.8.3): dist | place | seek | index | sketch\n");
+  if (sub.empty() || sub == "dist")
+    printf("\nkrepp dist -i DIR -q READS: distances of every read to the references it matches\n%s%s"
+           "      --filter / --no-filter keep only references not significantly worse than the closest [no-filter]\n",
+           query_opts, index_query_opts);
+  if (sub.empty() || sub == "place")
+    printf("\nkrepp place -i DIR -q READS: placements on the backbone tree (jplace)\n%s%s"
+           "  -t, --nwk-file PATH        rooted placement tree (overrides the index's backbone)\n"
+           "  -l, --lineage-file PATH    place on the taxonomy of a Greengenes/GTDB style lineage file\n"
+           "      --tau N                highest Hamming distance counted by the placement threshold [2]\n"
+           "      --filter / --no-filter [filter]\n"
+           "      --tabular              tab-separated rows instead of jplace\n",
+           query_opts, index_query_opts);
+  if (sub.empty() || sub == "seek")
+    printf("\nkrepp seek -i SKETCH -q READS: distance of every read to the one sketched reference\n"
+           "  -i, --sketch-path PATH     sketch file (as written by `krepp sketch`)\n%s", query_opts);
+  if (sub.empty() || sub == "index")
+    printf("\nkrepp index -i MAP.tsv -o DIR: build an index (reference ID <tab> FASTA path per line)\n"
+           "  -t, --nwk-file PATH        rooted guide tree (default: a balanced tree over the IDs)\n%s"
+           "      --num-threads N        CPU threads of the builder [1]\n"
+           "      --gpu-minimizers       window minimizers of the genomes on the GPU (identical output)\n",
+           build_opts);
+  if (sub.empty() || sub == "sketch")
+    printf("\nkrepp sketch -i GENOME.fa -o SKETCH: sketch of a single FASTA/FASTQ file (default k 26)\n%s", build_opts);
+  printf("\nEnvironment knobs and what differs from the reference: INTEGRATION.md\n");
+}
+
 static Args parse(int argc, char** argv)
 {
   Args a;
   for (int i = 1; i < argc; ++i) {
     std::string t = argv[i];
-    if (t == "--help") {
-      printf("krepp (MI355X build): sub-commands `dist`, `place`, `seek`, `index`, `sketch`; see INTEGRATION.md\n");
+    if (t == "--help" || (t == "-h" && a.sub.empty())) {
+      print_help(a.sub);
       exit(0);
     }
     if (t[0] != '-') {
