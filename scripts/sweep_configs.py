@@ -8,7 +8,8 @@ import numpy as np
 from krepp_amd import capi, synth
 import pyoracle as po
 nwk = "((a:0.02,b:0.02):0.02,(c:0.03,(d:0.01,e:0.01):0.02):0.01,(f:0.05,g:0.002):0.01);"
-g = synth.evolve_genomes(nwk, 30000, seed=9)
+SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 9
+g = synth.evolve_genomes(nwk, 30000, seed=SEED)
 work = tempfile.mkdtemp(prefix="krepp_sweep_")
 tsv = synth.write_genomes(g, os.path.join(work, "g"))
 open(os.path.join(work, "t.nwk"), "w").write(nwk)
@@ -16,7 +17,7 @@ cfgs = []
 for k, h in ((19, 3), (21, 7), (24, 8), (26, 10), (29, 13), (31, 15), (31, 16) if False else (30, 14)):
     for m, r, frac in ((1, 0, True), (2, 1, False), (3, 1, True), (4, 3, True), (4, 0, False), (7, 2, True)):
         cfgs.append((k, k + ((k * 7 + m) % 9), h, m, r, frac))
-rng = np.random.default_rng(1)
+rng = np.random.default_rng(SEED)
 bad = 0
 for ci, (k, w, h, m, r, frac) in enumerate(cfgs):
     idx = os.path.join(work, f"ix{ci}")
@@ -26,7 +27,7 @@ for ci, (k, w, h, m, r, frac) in enumerate(cfgs):
         print("cfg", (k, w, h, m, r, frac), "build refused:", e)
         continue
     hx = capi.HostIndex(idx); dx = hx.upload(0); ox = po.Index(idx)
-    for th, L in ((4, 150), (1, 100), (6, 151), (9, 260), (0, 90)):
+    for th, L in ((4, 150), (1, 100), (6, 151), (9, 260), (0, 90), (4, int(rng.integers(29, 900))), (int(rng.integers(0, 12)), int(rng.integers(60, 400)))):
         if th > 16 or (k - h) < 1:
             continue
         bases, offs, rn = synth.sample_reads(g, 300, seed=int(rng.integers(1 << 30)), length=L)
@@ -59,4 +60,6 @@ for ci, (k, w, h, m, r, frac) in enumerate(cfgs):
         st.close()
     print("cfg", (k, w, h, m, r, frac), "done", flush=True)
     dx.close()
+    import shutil
+    shutil.rmtree(idx, ignore_errors=True)  # h = 14, 15: the bucket-offset file alone is GBs
 print("sweep finished, mismatching cases:", bad)
