@@ -258,7 +258,7 @@ typedef struct kr_fastx kr_fastx;
 typedef struct kr_fastx_batch {
   const uint8_t* bases;
   const uint64_t* offsets;     /* [nreads+1] */
-  const char* const* names;    /* [nreads]   */
+  const char* const* names;    /* [nreads]   NUL-terminated, back to back in one buffer, in order */
   uint32_t nreads;
   uint32_t more;               /* 0 once the input is exhausted                    */
 } kr_fastx_batch;

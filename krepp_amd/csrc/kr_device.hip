@@ -658,6 +658,12 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
     s->in.offsets = s->d_offsets;
   }
   s->in.nreads = nreads;
+  { // about four chunks' worth of reads per wave, between 32 and kRecChunk slots (one shared counter serves ~90 M atomics/s:
+    // a million-read batch must not take its slots 32 at a time)
+    uint32_t per_wave = (uint32_t)std::min<uint64_t>(4ull * nreads / std::max<uint32_t>(1u, s->nwaves_lean), kRecChunk), c = 32;
+    while (c < per_wave) c <<= 1;
+    s->out.rec_chunk = std::min<uint32_t>(c, kRecChunk);
+  }
   HIP_TRY(hipMemsetAsync(s->out.counters, 0, 128, st));
   HIP_TRY(hipMemsetAsync(s->out.cursors, 0, 3 * kCursors * kCursorStride * 4, st));
   HIP_TRY(hipMemsetAsync(s->out.rec_key, 0, (uint64_t)s->rec_cap * 4, st));

@@ -138,7 +138,8 @@ struct Job {
   uint64_t seq = 0;
   std::vector<uint8_t> bases;
   std::vector<uint64_t> offsets;
-  std::vector<std::string> names;
+  std::string name_blob;            // the names, NUL-terminated, back to back (one allocation instead of one per read)
+  std::vector<const char*> names;   // pointers into name_blob
   std::string text;
   std::vector<kr_placement> pls; // place --summarize: the placements, `read` = global read number
   uint64_t first_read = 0;
@@ -275,8 +276,7 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
         todo.pop_front();
       }
       cv_work.notify_all(); // the reader may be waiting for queue space
-      std::vector<const char*> nm(j->names.size());
-      for (size_t i = 0; i < nm.size(); ++i) nm[i] = j->names[i].c_str();
+      const std::vector<const char*>& nm = j->names;
       std::string text;
       std::vector<kr_placement> pls;
       // reads [lo, hi) of the job; a batch that overflows a device-side buffer (KR_ERR_CAPACITY: unusually many
@@ -421,7 +421,14 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
       j->bases.assign(b.bases + b.offsets[r0], b.bases + b.offsets[r1]);
       j->offsets.resize(r1 - r0 + 1);
       for (uint32_t i = r0; i <= r1; ++i) j->offsets[i - r0] = b.offsets[i] - b.offsets[r0];
-      for (uint32_t i = r0; i < r1; ++i) j->names.emplace_back(b.names[i]);
+      { // the reader keeps a batch's names back to back in one buffer, in order (include/krepp_amd.h)
+        const char* first = b.names[r0];
+        const char* last = b.names[r1 - 1];
+        const size_t bytes = (size_t)(last - first) + strlen(last) + 1;
+        j->name_blob.assign(first, bytes);
+        j->names.resize(r1 - r0);
+        for (uint32_t i = r0; i < r1; ++i) j->names[i - r0] = j->name_blob.data() + (b.names[i] - first);
+      }
       j->first_read = nreads_total;
       nreads_total += r1 - r0;
       {

@@ -24,10 +24,8 @@ with open(fq, "wb") as f:
         f.write(b"".join(rows))
         done += m
 exe = os.path.join(root, "krepp_amd", "lib", "krepp")
-for sub, extra, env in (("dist", [], {}), ("dist", [], {"KR_CLI_BATCH_READS": "131072"}), ("dist", [], {"KR_CLI_BATCH_READS": "262144"}),
-                        ("dist", [], {"KR_CLI_WORKERS_PER_GPU": "3"}), ("dist", ["--summarize"], {}),
-                        ("place", [], {}), ("place", [], {"KR_CLI_BATCH_READS": "131072"}), ("place", [], {"KR_CLI_WORKERS_PER_GPU": "3"}),
-                        ("place", ["--tabular"], {}), ("place", ["--summarize"], {})):
+for sub, extra, env in (("dist", [], {}), ("dist", [], {"KR_CLI_WORKERS_PER_GPU": "3"}), ("dist", ["--summarize"], {}),
+                        ("place", [], {}), ("place", ["--tabular"], {}), ("place", ["--summarize"], {})):
     t = time.time()
     r = subprocess.run([exe, sub, "-i", idx, "-q", fq, "-o", os.path.join(work, "out.txt")] + extra, capture_output=True, text=True,
                        env=dict(os.environ, KR_CLI_TIMING="1", **env))
