@@ -292,7 +292,8 @@ bool lineage_tree(const char* text, kr_place_tree& pt, std::string& err)
     n.label = nd[c].name;
     n.blen = NAN;
     n.parent = nd[c].parent < 0 ? 0 : se[nd[c].parent];
-    n.kind = nd[c].kids.empty() ? 1 : 2;
+    n.kind = nd[c].kids.empty() ? 1 : 2; // a taxon left childless (its name reused under another parent) ends the path: the
+                                          // reference's traversal would walk off an empty child list there (src/phytree.cpp:266-267)
     pt.card[se[c]] = nd[c].card;
   }
   return true;

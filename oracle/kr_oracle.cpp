@@ -492,6 +492,10 @@ struct Tree {
     }
     for (int nd : order)
       if (nodes[nd].parent < 0) attach(nd, root);
+    // A taxon left without children (only when a later taxon of its lineage already existed under another parent)
+    // makes the reference's traversal walk off an empty child list (src/phytree.cpp:266-267); here it ends the path.
+    for (auto& nd : nodes)
+      if (nd.children.empty()) nd.is_leaf = true;
     number_post_order(root);
     return true;
   }

@@ -150,13 +150,21 @@ def test_oracle_lineage_tree(po, toy_index_dir, toy_reads):
     assert ox.place_frame(0, 2, "inv").endswith("DISTAL_NODE\tEDGE_NUM\tWEIGHTED_COUNT\tSEQUENCE_ABUNDANCE\n")
 
 
+# a taxon whose name comes back under another parent keeps its first parent; "D" is then left without children
+# (the reference's traversal is undefined there): it ends its path like a leaf
+LINEAGES_REUSED = "G1\tk__A; p__B\nG2\tk__C; p__D; p__B\n"
+LINEAGES_REUSED_NWK = "(((G1{0},G2{1})B{2})A{3},(D{4})C{5})root{6};"
+
+
 def test_host_lineage_tree_matches_oracle(capi, po, toy_index_dir):
     """kr_place_tree_create_lineage / kr_place_frame are host-only: no GPU needed."""
     import ctypes as C
     lib = capi.load()
     hx = capi.HostIndex(toy_index_dir)
     ox = po.Index(toy_index_dir)
-    for lin in (LINEAGES_SMALL, open(os.path.join(GOLDEN, "lineages_toy.txt")).read()):
+    ox.set_lineage_tree(LINEAGES_REUSED)
+    assert ox.place_frame(1, False, "i", 0).split('"tree" : "')[1].split('"')[0] == LINEAGES_REUSED_NWK
+    for lin in (LINEAGES_SMALL, LINEAGES_REUSED, open(os.path.join(GOLDEN, "lineages_toy.txt")).read()):
         ox.set_lineage_tree(lin)
         pt = C.c_void_p()
         capi.check(lib.kr_place_tree_create_lineage(hx.h, lin.encode(), C.byref(pt)))
