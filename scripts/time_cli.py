@@ -32,3 +32,17 @@ for sub, extra, env in (("dist", [], {}), ("dist", [], {"KR_CLI_WORKERS_PER_GPU"
     dt = time.time() - t
     print(sub, extra, env, [l for l in r.stderr.strip().splitlines() if "timing" in l or "elapsed" in l])
     print(sub, " ".join(extra), "rc", r.returncode, "reads", n, "seconds %.2f" % dt, "reads/s %.3g" % (n / dt), "output MB %.1f" % (os.path.getsize(os.path.join(work, "out.txt")) / 1e6))
+
+# gzip input: inflated by one thread (zlib), parsed by the sequential reader
+import shutil
+if shutil.which("gzip"):
+    ngz = min(n, 4_000_000)
+    fqs = os.path.join(work, "sub.fq")
+    with open(fq, "rb") as fi, open(fqs, "wb") as fo:
+        for _ in range(ngz * 4):
+            fo.write(fi.readline())
+    subprocess.run(["gzip", "-1", "-f", fqs], check=True)
+    t = time.time()
+    r = subprocess.run([exe, "dist", "-i", idx, "-q", fqs + ".gz", "-o", os.path.join(work, "out.txt")], capture_output=True, text=True,
+                       env=dict(os.environ, KR_CLI_TIMING="1"))
+    print("dist on .gz", ngz, "reads", [l for l in r.stderr.strip().splitlines() if "timing" in l or "elapsed" in l])
