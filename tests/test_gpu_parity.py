@@ -362,18 +362,26 @@ def test_large_clade_colours_spill_the_work_stack(capi, po, synth, tmp_path):
     hx = capi.HostIndex(idx)
     dx = hx.upload(0)
     ox = po.Index(idx)
-    bases, offs, rn = synth.sample_reads(g, 120, seed=3, length=150)
-    ref = ox.dist(bases, offs, rn, po.params(collect=7, num_threads=8))
-    acc = ref["accs"][ref["accs"]["passed"] == 1]
-    want = sorted(zip(acc["read"].tolist(), ((acc["se"] << 1) | acc["strand"]).tolist(), [tuple(x[:5]) for x in acc["hist"].tolist()]))
-    assert len(want) > 100 * 1000  # most reads reach most of the tree
-    st = dx.stream(max_reads=120, max_bases=len(bases), max_records=120 * 2 * n + 4096)
-    st.submit(bases, offs, capi.KR_TAP_ACCS)
-    res = st.collect()
-    got = sorted(zip(res.rec_read.tolist(), res.rec_key.tolist(), [tuple(x) for x in res.rec_hist.tolist()]))
-    assert got == want
-    assert_rows_close(res.rows(), rows_of_oracle(ref))
-    assert st.timing().stack_spills > 0
+    spills = 0
+    for length, dbg, nreads in ((150, "0", 120), (150, "8", 40), (300, "0", 40), (300, "8192", 40)):
+        bases, offs, rn = synth.sample_reads(g, nreads, seed=3 + length, length=length)
+        ref = ox.dist(bases, offs, rn, po.params(collect=7, num_threads=8))
+        acc = ref["accs"][ref["accs"]["passed"] == 1]
+        want = sorted(zip(acc["read"].tolist(), ((acc["se"] << 1) | acc["strand"]).tolist(), [tuple(x[:5]) for x in acc["hist"].tolist()]))
+        assert len(want) > nreads * 800  # most reads reach most of the tree
+        os.environ["KR_DEBUG_SKIP"] = dbg
+        try:
+            st = dx.stream(max_reads=nreads, max_bases=len(bases), max_records=nreads * 2 * n + 4096)
+            st.submit(bases, offs, capi.KR_TAP_ACCS)
+            res = st.collect()
+        finally:
+            del os.environ["KR_DEBUG_SKIP"]
+        got = sorted(zip(res.rec_read.tolist(), res.rec_key.tolist(), [tuple(x) for x in res.rec_hist.tolist()]))
+        assert got == want, (length, dbg)
+        assert_rows_close(res.rows(), rows_of_oracle(ref))
+        spills += st.timing().stack_spills
+        st.close()
+    assert spills > 0
 
 
 @pytest.mark.parametrize("cfg", [(19, 24, 3, 1, 0, True), (21, 21, 7, 2, 1, False), (24, 31, 8, 3, 1, True), (26, 32, 10, 4, 3, True),
