@@ -532,7 +532,7 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   { // per-wave global scratch grows with the tree (100 B per leaf for the level-2 tables): bound the total by running
     // fewer waves on very large trees (reads are handed out dynamically, so any grid size is correct)
     const uint64_t np_ = p->hdist_th + 1;
-    const uint64_t per_wave = (uint64_t)nslots2 * np_ * (kPlaneWords + 1) * 4 + (uint64_t)std::max<uint32_t>(nslots2, kEvSpill + 8192u) * 4;
+    const uint64_t per_wave = (uint64_t)nslots2 * np_ * (kPlaneWords + 1) * 4 + (uint64_t)std::max<uint32_t>(nslots2, kEvSpill + 4u * 16384u) * 4;
     const uint64_t budget = (getenv("KR_ACC_SCRATCH_GB") ? (uint64_t)atoi(getenv("KR_ACC_SCRATCH_GB")) : 16ull) << 30;
     const uint32_t max_waves = (uint32_t)std::max<uint64_t>((uint64_t)prop.multiProcessorCount, budget / per_wave);
     s->nwaves_full = std::min(s->nwaves_full, max_waves);
@@ -591,8 +591,8 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   SA(o.stk_spill, (uint64_t)s->nwaves * kStackSpill);
   o.nslots2 = nslots2;
   o.ev_spill = kEvSpill;
-  o.tab_spill = std::min<uint32_t>(nslots2, 4096u);
-  o.kt_spill = std::min<uint32_t>(nslots2, 16384u);
+  o.tab_spill = std::min<uint32_t>(nslots2, 16384u);
+  o.kt_spill = std::min<uint32_t>(nslots2, 65536u);
   const uint32_t g_list_words = std::max<uint32_t>(nslots2, o.ev_spill + o.tab_spill * ((np + 3) / 4 + 1) + o.kt_spill);
   o.g_list_words = g_list_words;
   o.bm_words = bm_words;
