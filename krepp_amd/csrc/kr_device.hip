@@ -532,7 +532,9 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   { // per-wave global scratch grows with the tree (100 B per leaf for the level-2 tables): bound the total by running
     // fewer waves on very large trees (reads are handed out dynamically, so any grid size is correct)
     const uint64_t np_ = p->hdist_th + 1;
-    const uint64_t per_wave = (uint64_t)nslots2 * np_ * (kPlaneWords + 1) * 4 + (uint64_t)std::max<uint32_t>(nslots2, kEvSpill + 4u * 16384u) * 4;
+    const uint64_t tab_spill = std::min<uint32_t>(nslots2, 16384u), kt_spill = std::min<uint32_t>(nslots2, 65536u); // as below
+    const uint64_t list_words = std::max<uint64_t>(nslots2, kEvSpill + tab_spill * ((np_ + 3) / 4 + 1) + kt_spill);
+    const uint64_t per_wave = (uint64_t)nslots2 * np_ * (kPlaneWords + 1) * 4 + list_words * 4 + (uint64_t)kStackSpill * 8;
     const uint64_t budget = (getenv("KR_ACC_SCRATCH_GB") ? (uint64_t)atoi(getenv("KR_ACC_SCRATCH_GB")) : 16ull) << 30;
     const uint32_t max_waves = (uint32_t)std::max<uint64_t>((uint64_t)prop.multiProcessorCount, budget / per_wave);
     s->nwaves_full = std::min(s->nwaves_full, max_waves);
