@@ -13,6 +13,7 @@
 #include "kr_common.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -898,8 +899,197 @@ struct FqPool {
 };
 } // namespace
 
+// ---- block-gzipped input (BGZF: a gzip file made of independent members of <= 64 KB, each announcing its
+// compressed size in a "BC" extra field and its inflated size in its trailer) ------------------------------------
+// Ordinary gzip is one dependent stream and is inflated by one thread (zlib, below).  BGZF members are independent:
+// the reader walks the member headers, hands runs of members to a few threads (raw inflate + CRC check each) and
+// consumes the inflated runs in file order, like gzread would deliver them.
+struct BgzfSource {
+  struct Buf { // grows, never shrinks, not zero-filled: runs are recycled (fresh multi-MB allocations per run cost more
+               // in page faults than the inflate they hold)
+    std::unique_ptr<unsigned char[]> p;
+    size_t cap = 0, len = 0;
+    unsigned char* ensure(size_t n)
+    {
+      if (n > cap) p.reset(new unsigned char[n + n / 4 + 64]), cap = n + n / 4 + 64;
+      len = n;
+      return p.get();
+    }
+  };
+  struct Run {
+    uint64_t off = 0, bytes = 0; // compressed range
+    Buf in, out;
+    bool ok = false, ready = false;
+  };
+  std::vector<std::unique_ptr<Run>> spare;
+  int fd = -1;
+  uint64_t size = 0, next_off = 0;
+  bool issued_all = false, failed = false;
+  size_t depth = 0;
+  std::deque<std::unique_ptr<Run>> inflight;
+  std::deque<Run*> todo;
+  std::mutex mu;
+  std::condition_variable cv_todo, cv_ready;
+  bool stop = false;
+  std::vector<std::thread> threads;
+  std::unique_ptr<Run> cur;
+  size_t cur_pos = 0;
+
+  // size of the member at `off` (0: not a BGZF member / end of file)
+  static uint32_t member_size(const unsigned char* h, size_t avail)
+  {
+    if (avail < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return 0;
+    const uint32_t xlen = h[10] | (h[11] << 8);
+    if (avail < 12 + (size_t)xlen) return 0;
+    for (uint32_t p = 12; p + 4 <= 12 + xlen;) {
+      const uint32_t slen = h[p + 2] | (h[p + 3] << 8);
+      if (h[p] == 'B' && h[p + 1] == 'C' && slen == 2 && p + 6 <= 12 + xlen) return (uint32_t)(h[p + 4] | (h[p + 5] << 8)) + 1u;
+      p += 4 + slen;
+    }
+    return 0;
+  }
+  static bool is_bgzf(int fd)
+  {
+    unsigned char h[64];
+    const ssize_t n = pread(fd, h, sizeof(h), 0);
+    return n >= 18 && member_size(h, (size_t)n) != 0;
+  }
+  void inflate_run(Run& r, z_stream& zs)
+  {
+    unsigned char* const in = r.in.ensure((size_t)r.bytes);
+    const size_t in_len = (size_t)r.bytes;
+    if (!FqPool::pread_all(fd, in, r.off, in_len)) return;
+    // pass 1: member boundaries and inflated sizes
+    std::vector<std::array<uint64_t, 3>> mem; // offset in `in`, compressed size, offset in `out`
+    uint64_t p = 0, total = 0;
+    while (p < in_len) {
+      const uint32_t ms = member_size(in + p, in_len - p);
+      if (ms < 28 || p + ms > in_len) return;
+      const unsigned char* t = in + p + ms - 4;
+      const uint32_t isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+      mem.push_back({p, ms, total});
+      total += isize;
+      p += ms;
+    }
+    unsigned char* const outp = r.out.ensure((size_t)total);
+    for (auto& m : mem) {
+      const unsigned char* h = in + m[0];
+      const uint32_t xlen = h[10] | (h[11] << 8), ms = (uint32_t)m[1];
+      const unsigned char* t = h + ms - 8;
+      const uint32_t crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+      const uint32_t isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((uint32_t)t[7] << 24);
+      if (inflateReset(&zs) != Z_OK) return;
+      zs.next_in = const_cast<unsigned char*>(h + 12 + xlen);
+      zs.avail_in = ms - 12 - xlen - 8;
+      zs.next_out = outp + m[2];
+      zs.avail_out = isize;
+      const int rc = inflate(&zs, Z_FINISH);
+      if (rc != Z_STREAM_END || zs.avail_out != 0) return;
+      if (crc32(crc32(0L, Z_NULL, 0), outp + m[2], isize) != crc) return;
+    }
+    r.ok = true;
+  }
+  void work()
+  {
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) return;
+    for (;;) {
+      Run* r = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_todo.wait(lk, [&] { return stop || !todo.empty(); });
+        if (stop) break;
+        r = todo.front();
+        todo.pop_front();
+      }
+      inflate_run(*r, zs);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        r->ready = true;
+      }
+      cv_ready.notify_all();
+    }
+    inflateEnd(&zs);
+  }
+  void issue()
+  { // walk the member headers: runs of about 1 MB of compressed data
+    while (!issued_all && inflight.size() < depth) {
+      uint64_t o = next_off;
+      unsigned char h[18 + 256];
+      while (o < size && o - next_off < (1u << 20)) {
+        const ssize_t n = pread(fd, h, sizeof(h), (off_t)o);
+        const uint32_t ms = n > 0 ? member_size(h, (size_t)n) : 0;
+        if (ms == 0 || o + ms > size) { // not a member where one must start: hand over what is complete, then fail
+          failed = o == next_off;
+          issued_all = true;
+          break;
+        }
+        o += ms;
+      }
+      if (o >= size) issued_all = true;
+      if (o == next_off) break;
+      std::unique_ptr<Run> r;
+      if (!spare.empty()) r = std::move(spare.back()), spare.pop_back();
+      else r.reset(new Run());
+      r->ok = r->ready = false;
+      r->off = next_off, r->bytes = o - next_off;
+      next_off = o;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        todo.push_back(r.get());
+      }
+      inflight.push_back(std::move(r));
+      cv_todo.notify_one();
+    }
+  }
+  // like gzread: up to n bytes, 0 at the end, -1 on a damaged file
+  int read(unsigned char* dst, unsigned n)
+  {
+    for (;;) {
+      if (cur && cur_pos < cur->out.len) {
+        const unsigned k = (unsigned)std::min<size_t>(n, cur->out.len - cur_pos);
+        memcpy(dst, cur->out.p.get() + cur_pos, k);
+        cur_pos += k;
+        return (int)k;
+      }
+      if (cur) spare.push_back(std::move(cur)); // only this thread touches `spare`
+      cur.reset();
+      issue();
+      if (inflight.empty()) return (failed || next_off < size) ? -1 : 0;
+      cur = std::move(inflight.front());
+      inflight.pop_front();
+      cur_pos = 0;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_ready.wait(lk, [&] { return cur->ready; });
+      }
+      if (!cur->ok) {
+        failed = true;
+        cur.reset();
+        return -1;
+      }
+      issue();
+    }
+  }
+  void shutdown()
+  {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_todo.notify_all();
+    for (auto& t : threads) t.join();
+    threads.clear();
+    if (fd >= 0) close(fd);
+    fd = -1;
+  }
+};
+
 struct kr_fastx {
   gzFile f = nullptr;
+  std::unique_ptr<BgzfSource> bgzf; // block-gzipped input: members inflated in parallel
+  bool bgzf_error = false;
   std::string path;
   std::unique_ptr<FqPool> pool; // plain files: chunks parsed in parallel while this is set
   uint64_t pool_chunks = 0;     // chunks accepted from the pool
@@ -919,7 +1109,8 @@ struct kr_fastx {
   {
     if (pos >= end) {
       if (eof) return -1;
-      int n = gzread(f, buf.data(), (unsigned)buf.size());
+      int n = bgzf ? bgzf->read(buf.data(), (unsigned)buf.size()) : gzread(f, buf.data(), (unsigned)buf.size());
+      if (bgzf && n < 0) bgzf_error = true;
       if (n <= 0) {
         eof = true;
         return -1;
@@ -940,7 +1131,8 @@ struct kr_fastx {
       pos = 0;
     }
     while (end < buf.size()) {
-      int n = gzread(f, buf.data() + end, (unsigned)(buf.size() - end));
+      int n = bgzf ? bgzf->read(buf.data() + end, (unsigned)(buf.size() - end)) : gzread(f, buf.data() + end, (unsigned)(buf.size() - end));
+      if (bgzf && n < 0) bgzf_error = true;
       if (n <= 0) {
         eof = true;
         break;
@@ -1045,7 +1237,13 @@ int kr_fastx_open(const char* path, kr_fastx** out)
     const bool regular = nt && stat(path, &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size >= par_min; // never a pipe
     int fd = regular ? open(path, O_RDONLY) : -1;
     unsigned char magic[2] = {0, 0};
-    if (fd >= 0 && pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+    if (fd >= 0 && BgzfSource::is_bgzf(fd)) {
+      r->bgzf.reset(new BgzfSource());
+      r->bgzf->fd = fd;
+      r->bgzf->size = (uint64_t)sb.st_size;
+      r->bgzf->depth = 2 * nt;
+      for (unsigned t = 0; t < nt; ++t) r->bgzf->threads.emplace_back([p = r->bgzf.get()] { p->work(); });
+    } else if (fd >= 0 && pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
       r->pool.reset(new FqPool());
       r->pool->fd = fd;
       r->pool->size = (uint64_t)sb.st_size;
@@ -1113,6 +1311,7 @@ int kr_fastx_next(kr_fastx* r, uint64_t min_bases, kr_fastx_batch* out)
     r->name_blob += name;
     r->name_blob.push_back('\0');
   }
+  if (r->bgzf_error) return kr::fail(KR_ERR_IO, "damaged block-gzipped file (a member does not inflate or fails its CRC): " + r->path);
   r->name_ptrs.resize(r->name_off.size());
   for (size_t i = 0; i < r->name_off.size(); ++i) r->name_ptrs[i] = r->name_blob.c_str() + r->name_off[i];
   out->bases = r->bases.data();
@@ -1129,6 +1328,7 @@ void kr_fastx_close(kr_fastx* r)
 {
   if (!r) return;
   if (r->pool) r->pool->shutdown();
+  if (r->bgzf) r->bgzf->shutdown();
   if (r->f) gzclose(r->f);
   delete r;
 }

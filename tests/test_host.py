@@ -184,6 +184,60 @@ def test_parallel_fastq_reader_equals_sequential(capi, tmp_path):
             assert seq_res[0][2000:] == ks["edge"]["names"]
 
 
+def _bgzf_bytes(data, block=60000, level=1):
+    """block-gzipped form of `data`: independent gzip members with a BC extra field, plus the empty EOF member"""
+    import struct
+    import zlib
+    out = bytearray()
+    chunks = [data[i:i + block] for i in range(0, len(data), block)] + [b""]
+    for c in chunks:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = co.compress(c) + co.flush()
+        bsize = 12 + 6 + len(comp) + 8 - 1
+        out += b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize)
+        out += comp + struct.pack("<II", zlib.crc32(c) & 0xFFFFFFFF, len(c))
+    return bytes(out)
+
+
+def test_block_gzipped_input_is_inflated_in_parallel(capi, tmp_path):
+    """BGZF files (bgzip, many sequencing pipelines): the members are inflated by several threads; the records are
+    those of the plain file, standard tools still read the file, a damaged member is an error, not a silent stop."""
+    rng = np.random.default_rng(9)
+    recs = []
+    for i in range(9000):
+        n = int(rng.integers(1, 260))
+        recs.append(b"@r%d c\n" % i + rng.choice(np.frombuffer(b"ACGTN", np.uint8), n).tobytes() + b"\n+\n" + b"I" * n + b"\n")
+    data = b"".join(recs) + b">tail\nACGT\nAC\n"
+    plain, bg = tmp_path / "a.fq", tmp_path / "a.fq.gz"
+    plain.write_bytes(data)
+    bg.write_bytes(_bgzf_bytes(data))
+    assert gzip.open(bg).read() == data  # a valid multi-member gzip file
+    os.environ["KR_FASTX_PAR_MIN"] = "0"
+    try:
+        want = capi.read_fastx(str(plain), min_bases=50000)
+        for threads in ("3", "1"):
+            os.environ["KR_FASTX_THREADS"] = threads
+            got = capi.read_fastx(str(bg), min_bases=50000)
+            assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+        os.environ["KR_FASTX_THREADS"] = "0"  # zlib stream reader on the same file
+        got = capi.read_fastx(str(bg), min_bases=50000)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1])
+        os.environ["KR_FASTX_THREADS"] = "3"
+        raw = bytearray(bg.read_bytes())
+        raw[len(raw) // 2] ^= 0x55  # flip bits in the middle of some member
+        bad = tmp_path / "bad.fq.gz"
+        bad.write_bytes(bytes(raw))
+        with pytest.raises(capi.KrError):
+            capi.read_fastx(str(bad), min_bases=50000)
+        trunc = tmp_path / "trunc.fq.gz"
+        trunc.write_bytes(bg.read_bytes()[: len(raw) // 2])
+        with pytest.raises(capi.KrError):
+            capi.read_fastx(str(trunc), min_bases=50000)
+    finally:
+        os.environ.pop("KR_FASTX_PAR_MIN", None)
+        os.environ.pop("KR_FASTX_THREADS", None)
+
+
 def test_builder_output_is_consistent_with_brute_force(capi, po, synth, tmp_path):
     """Independent check of the CPU builder: recompute, in pure Python, the minimizers of tiny
     genomes (src/rqseq.cpp:51-144 semantics) and the genome set of every indexed k-mer, and
