@@ -253,6 +253,9 @@ KR_API int kr_batch_timing(kr_stream*, kr_timing* out);
 /* QSeq (src/rqseq.cpp:146-203): gz/FASTA/FASTQ batches of >= 76,800 bases.  Plain (uncompressed)   */
 /* regular files of >= 32 MB are cut at record starts and parsed by a thread pool (KR_FASTX_THREADS,   */
 /* default min(8, cores/2); 0 = off): a batch is then one chunk of about 2 * min_bases bytes of input. */
+/* Block-gzipped files (BGZF: independent members with a "BC" extra field) are inflated member by       */
+/* member on the same threads (CRC-checked; a damaged member is KR_ERR_IO); ordinary gzip is one stream  */
+/* and is inflated by zlib in the calling thread.                                                        */
 /* Records, names and order are those of the sequential reader in every case.                          */
 typedef struct kr_fastx kr_fastx;
 typedef struct kr_fastx_batch {
