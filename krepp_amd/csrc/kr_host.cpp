@@ -925,6 +925,7 @@ struct BgzfSource {
   int fd = -1;
   uint64_t size = 0, next_off = 0;
   bool issued_all = false, failed = false;
+  uint64_t trunc_at = UINT64_MAX; // offset of a member that the file ends in the middle of
   size_t depth = 0;
   std::deque<std::unique_ptr<Run>> inflight;
   std::deque<Run*> todo;
@@ -1020,9 +1021,9 @@ struct BgzfSource {
       while (o < size && o - next_off < (1u << 20)) {
         const ssize_t n = pread(fd, h, sizeof(h), (off_t)o);
         const uint32_t ms = n > 0 ? member_size(h, (size_t)n) : 0;
-        if (ms == 0 || o + ms > size) { // not a member where one must start: hand over what is complete, then fail
-          failed = o == next_off;
-          issued_all = true;
+        if (ms == 0 || o + ms > size) { // hand over what is complete; then: a member cut short by the end of the file
+          trunc_at = ms ? o : UINT64_MAX; // is an error, anything that is not a BGZF member (an ordinary gzip member
+          issued_all = true;              // appended to the file, say) is zlib's from there on
           break;
         }
         o += ms;
@@ -1056,7 +1057,10 @@ struct BgzfSource {
       if (cur) spare.push_back(std::move(cur)); // only this thread touches `spare`
       cur.reset();
       issue();
-      if (inflight.empty()) return (failed || next_off < size) ? -1 : 0;
+      if (inflight.empty()) { // -2: continue with zlib at next_off
+        if (failed || trunc_at == next_off) return -1;
+        return next_off < size ? -2 : 0;
+      }
       cur = std::move(inflight.front());
       inflight.pop_front();
       cur_pos = 0;
@@ -1105,11 +1109,38 @@ struct kr_fastx {
   std::vector<size_t> name_off;
   std::vector<const char*> name_ptrs;
 
+  // the block-gzipped part of the file has ended before the file has: what follows (an ordinary gzip member
+  // appended with `cat`, say) is zlib's, from that offset on
+  bool leave_bgzf()
+  {
+    const uint64_t off = bgzf->next_off;
+    bgzf->shutdown();
+    bgzf.reset();
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0 || lseek(fd, (off_t)off, SEEK_SET) < 0) {
+      if (fd >= 0) close(fd);
+      return false;
+    }
+    gzFile g = gzdopen(fd, "rb");
+    if (!g) {
+      close(fd);
+      return false;
+    }
+    gzbuffer(g, 1 << 20);
+    if (f) gzclose(f);
+    f = g;
+    return true;
+  }
+
   int getc()
   {
     if (pos >= end) {
       if (eof) return -1;
       int n = bgzf ? bgzf->read(buf.data(), (unsigned)buf.size()) : gzread(f, buf.data(), (unsigned)buf.size());
+      if (bgzf && n == -2) {
+        if (leave_bgzf()) n = gzread(f, buf.data(), (unsigned)buf.size());
+        else n = -1, bgzf_error = true;
+      }
       if (bgzf && n < 0) bgzf_error = true;
       if (n <= 0) {
         eof = true;
@@ -1132,6 +1163,10 @@ struct kr_fastx {
     }
     while (end < buf.size()) {
       int n = bgzf ? bgzf->read(buf.data() + end, (unsigned)(buf.size() - end)) : gzread(f, buf.data() + end, (unsigned)(buf.size() - end));
+      if (bgzf && n == -2) {
+        if (leave_bgzf()) n = gzread(f, buf.data() + end, (unsigned)(buf.size() - end));
+        else n = -1, bgzf_error = true;
+      }
       if (bgzf && n < 0) bgzf_error = true;
       if (n <= 0) {
         eof = true;

@@ -229,6 +229,15 @@ def test_block_gzipped_input_is_inflated_in_parallel(capi, tmp_path):
         bad.write_bytes(bytes(raw))
         with pytest.raises(capi.KrError):
             capi.read_fastx(str(bad), min_bases=50000)
+        # block-gzipped members followed by an ordinary gzip member (cat a.bgz b.gz): zlib takes over where they end
+        extra = b"@x1\nACGTACGT\n+\nIIIIIIII\n>x2\nAC\n"
+        mixed = tmp_path / "mixed.fq.gz"
+        mixed.write_bytes(_bgzf_bytes(data[: len(data) - 14])[:-28] + gzip.compress(extra))  # without the EOF member
+        plain2 = tmp_path / "b.fq"
+        plain2.write_bytes(data[: len(data) - 14] + extra)
+        w2 = capi.read_fastx(str(plain2), min_bases=50000)
+        g2 = capi.read_fastx(str(mixed), min_bases=50000)
+        assert g2[0] == w2[0] and np.array_equal(g2[1], w2[1]) and g2[0][-2:] == ["x1", "x2"]
         trunc = tmp_path / "trunc.fq.gz"
         trunc.write_bytes(bg.read_bytes()[: len(raw) // 2])
         with pytest.raises(capi.KrError):
