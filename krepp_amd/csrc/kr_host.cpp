@@ -968,6 +968,7 @@ struct BgzfSource {
       if (ms < 28 || p + ms > in_len) return;
       const unsigned char* t = in + p + ms - 4;
       const uint32_t isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+      if (isize > (1u << 24)) return; // BGZF members inflate to at most 64 KB: a trailer that claims more is damage
       mem.push_back({p, ms, total});
       total += isize;
       p += ms;
