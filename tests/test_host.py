@@ -375,3 +375,21 @@ def test_cli_index_matches_library_builder(capi, synth, tmp_path):
     assert r.returncode == 0, r.stderr
     md = open(os.path.join(d3, "metadata-m64r0-no_frac"), "rb").read()
     assert (md[0], md[1], md[2]) == (23, 29, 7)
+
+
+def test_cli_help_and_usage_errors():
+    """No GPU needed: --help lists the sub-commands and their options; misuse ends like the reference's error_exit
+    (`[ERROR] ...` on stderr, status 1; src/common.cpp:20-24)."""
+    exe = os.path.join(ROOT, "krepp_amd", "lib", "krepp")
+    r = subprocess.run([exe, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0
+    for word in ("dist", "place", "seek", "index", "sketch", "--hdist-th", "--lineage-file", "--summarize", "--tabular", "--kmer-len"):
+        assert word in r.stdout, word
+    r = subprocess.run([exe, "place", "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "--tau" in r.stdout and "krepp index -i MAP.tsv" not in r.stdout
+    for args in (["dist"], ["bogus"], [], ["dist", "-i", "/nonexistent", "-q", "/nonexistent"], ["sketch", "-i", "x"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True)
+        assert r.returncode == 1 and "[ERROR]" in r.stderr, (args, r.stderr)
+    r = subprocess.run([exe, "dist", "-i", os.path.join(GOLDEN, "toy_index"), "-q", os.path.join(GOLDEN, "toy_reads.fq"), "--dist-max", "0.5"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "--dist-max" in r.stderr
