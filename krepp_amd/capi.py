@@ -350,9 +350,15 @@ class Result:
         self.rec_hist = (_np(rv.rec_hist, c * np_planes, np.uint32).reshape(np_planes, -1).T[keep]
                          if copy_hist and rv.rec_hist and c else (np.zeros((0, np_planes), np.uint32) if copy_hist else None))
         # read index of every record, and offsets into the compacted arrays
+        # (vectorised: a record belongs to the read whose first record is the last start at or before it)
         rr = np.zeros(c, np.uint32)
-        for r in np.nonzero(self.read_cnt)[0]:
-            rr[self.read_off[r]:self.read_off[r] + self.read_cnt[r]] = r
+        nzr = np.nonzero(self.read_cnt)[0]
+        if c and len(nzr):
+            start = np.zeros(c, np.int64)
+            start[self.read_off[nzr]] = self.read_off[nzr].astype(np.int64) + 1
+            at = np.zeros(c + 1, np.uint32)
+            at[self.read_off[nzr].astype(np.int64) + 1] = nzr
+            rr = at[np.maximum.accumulate(start)]
         self.rec_read = rr[keep]
         newpos = np.cumsum(keep) - 1
         nz = self.read_cnt > 0

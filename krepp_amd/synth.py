@@ -204,3 +204,76 @@ def yule_newick(n, seed, mean_blen=0.02, prefix="g"):
         items.append(f"({a}:{bl[bi]:.6f},{b}:{bl[bi + 1]:.6f})")
         bi += 2
     return items[0] + ";"
+
+
+def inflate_and_upload(torch, capi, hx, dev, local, index_gb, seed=20260101):
+    """BASELINE configs[2] index (SURVEY.md §8d-3 allows a direct synthetic writer): merge the REAL index `hx`
+    (CPU-built, real colour DAG) with uniformly random filler entries whose colours are random clades (a leaf
+    plus a geometric walk towards the root) until the cmer table holds `index_gb` GB, on the GPU with torch,
+    and upload the result from device memory (KR_VIEW_DEVICE).
+    Returns (DeviceIndex, (inc, cmer) numpy copies in the on-disk layout, for the oracle's replace_table)."""
+    import ctypes as C
+
+    la = hx.lib_arrays(0)
+    nrows = len(la["inc"])
+    real = torch.from_numpy(la["cmer"].astype(np.int64)).to(dev)  # (n, 2): enc32, se
+    rows_real = torch.repeat_interleave(torch.arange(nrows, device=dev, dtype=torch.int64),
+                                        torch.from_numpy(np.diff(np.concatenate([[0], la["inc"]]).astype(np.int64))).to(dev))
+    key_real = (rows_real << 32) | real[:, 0]
+    se_real = real[:, 1].to(torch.int32)
+    del real, rows_real
+    target = int(index_gb * 1e9 / 8)
+    nfill = max(0, target - key_real.numel())
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    kinds = hx.kinds()
+    nn = hx.nnodes
+    parent = torch.tensor([0] + [hx.parent(se) for se in range(1, nn + 1)], device=dev, dtype=torch.int32)
+    leaves = torch.tensor([se for se in range(1, nn + 1) if kinds[se] == 1], device=dev, dtype=torch.int32)
+    keys = [key_real]
+    ses = [se_real]
+    step = 1 << 27
+    for off in range(0, nfill, step):
+        m = min(step, nfill - off)
+        row = torch.randint(0, nrows, (m,), generator=gen, device=dev, dtype=torch.int64)
+        enc = torch.randint(0, 1 << 32, (m,), generator=gen, device=dev, dtype=torch.int64)
+        keys.append((row << 32) | enc)
+        se = leaves[torch.randint(0, leaves.numel(), (m,), generator=gen, device=dev)]
+        for _ in range(12):  # geometric number of steps towards the root: colour = a clade
+            up = torch.rand(m, generator=gen, device=dev) < 0.5
+            pa = parent[se.long()]
+            se = torch.where(up & (pa > 0), pa, se)
+            del up, pa
+        ses.append(se)
+        del row, enc
+    key = torch.cat(keys)
+    se = torch.cat(ses)
+    del keys, ses, key_real, se_real
+    key, order = torch.sort(key)
+    se = se[order]
+    del order
+    counts = torch.bincount(key >> 32, minlength=nrows)
+    inc = torch.cumsum(counts, 0)
+    del counts
+    cmer = torch.stack([(key & 0xFFFFFFFF).to(torch.int32), se], dim=1).contiguous()  # two's-complement u32 pairs
+    del key, se
+    pse = torch.from_numpy(la["pse"].astype(np.uint32).view(np.int32)).to(dev).contiguous()
+    rho = torch.from_numpy(la["rho"]).to(dev).contiguous()
+    torch.cuda.synchronize()
+    # same host view, big arrays swapped for the device tensors
+    lv = capi.KrLibView()
+    C.memmove(C.byref(lv), C.byref(hx.view.libs[0]), C.sizeof(lv))
+    lv.inc = C.cast(inc.data_ptr(), capi.u64p)
+    lv.cmer = C.cast(cmer.data_ptr(), capi.u32p)
+    lv.pse = C.cast(pse.data_ptr(), capi.u32p)
+    lv.rho = C.cast(rho.data_ptr(), capi.f64p)
+    lv.nkmers = cmer.shape[0]
+    view = capi.KrIndexView()
+    C.memmove(C.byref(view), C.byref(hx.view), C.sizeof(view))
+    arr = (capi.KrLibView * 1)(lv)
+    view.libs = arr
+    dx = capi.DeviceIndex.from_view(view, local, capi.KR_VIEW_DEVICE, keep=hx)
+    host = (inc.cpu().numpy().astype(np.uint64), cmer.cpu().numpy().view(np.uint32))
+    del inc, cmer, pse, rho
+    torch.cuda.empty_cache()
+    return dx, host

@@ -1,0 +1,113 @@
+"""BASELINE.json configs[2] under pytest: 150-bp reads against the 1000-genome index (Yule tree, default
+parameters -k 29 -w 35 -h 13, m4r1-frac: 2^25 rows) whose table is inflated to 10 GB resident in HBM — the
+exact index bench.py measures (krepp_amd.synth.inflate_and_upload, same seeds).
+
+Per table layout (the default slotted copy of the bucket heads, W = 64 words; and KR_SLOT_LOG2W=0, the packed
+table only): 20,000 reads against the oracle holding the same table (Index.replace_table) — table hits
+(src/query.cpp:352-368, src/index.cpp:160-168) and histograms (src/query.hpp:153-176) bit-exact, DIST within the
+north star's 1e-6 relative — then a full 1,000,000-read batch through the size-independent properties
+(reverse complement, permutation, split).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_rows_close, rows_of_oracle
+
+pytestmark = pytest.mark.gpu
+
+N_GENOMES, GENOME_LEN, INDEX_GB = 1000, 100_000, 10.0
+N_ORACLE, N_FULL = 20_000, 1_000_000
+
+
+@pytest.fixture(scope="module")
+def syn(capi, po, synth, tmp_path_factory):
+    work = tmp_path_factory.mktemp("syn1000")
+    nwk_text = synth.yule_newick(N_GENOMES, 2)
+    genomes = synth.evolve_genomes(nwk_text, GENOME_LEN, seed=2)
+    nwk = work / "yule.nwk"
+    nwk.write_text(nwk_text)
+    tsv = synth.write_genomes(genomes, str(work / "g"))
+    idx = str(work / "idx")
+    capi.build_index(tsv, idx, nwk=str(nwk), k=29, w=35, h=13, m=4, r=1, frac=True, num_threads=min(32, os.cpu_count() or 1))
+    return idx, genomes
+
+
+def make_reads(synth, genomes, n, seed):
+    chunks = [synth.sample_reads(genomes, min(100_000, n - o), seed=seed * 1000 + c)[0] for c, o in enumerate(range(0, n, 100_000))]
+    return np.concatenate(chunks), np.arange(n + 1, dtype=np.uint64) * np.uint64(150)
+
+
+@pytest.mark.parametrize("slot_log2w", [None, "0"], ids=["slotted_w64", "packed"])
+def test_syn1000_10gb_index_vs_oracle_and_full_batch_properties(capi, po, synth, syn, monkeypatch, slot_log2w):
+    import torch
+
+    idx, genomes = syn
+    if slot_log2w is not None:
+        monkeypatch.setenv("KR_SLOT_LOG2W", slot_log2w)
+    dev = torch.device("cuda", 0)
+    hx = capi.HostIndex(idx)
+    dx, (inc, cmer) = synth.inflate_and_upload(torch, capi, hx, dev, 0, INDEX_GB)
+    try:
+        nk = cmer.size // 2
+        assert len(inc) == 1 << 25 and nk * 8 >= 0.99 * INDEX_GB * 1e9
+        # slotted: 2^25 rows x 256 B of slots on top of the packed table; packed: no slots
+        assert (dx.device_bytes > 18e9) == (slot_log2w is None)
+        ox = po.Index(idx)
+        ox.replace_table(0, inc, cmer)
+        del inc, cmer
+
+        # ---- 20,000 reads: hits, histograms, rows against the oracle ----
+        bases, offs = make_reads(synth, genomes, N_ORACLE, seed=1)
+        ref = ox.dist(bases, offs, None, po.params(collect=3, num_threads=min(32, os.cpu_count() or 1)))
+        st = dx.stream(max_reads=N_ORACLE, max_bases=len(bases), max_records=N_ORACLE * 256)
+        st.submit(bases, offs, capi.KR_TAP_ACCS | capi.KR_TAP_HITS)
+        res = st.collect()
+        gh, rh = st.hits(), ref["hits"]
+        assert len(gh) == len(rh) and len(rh) > 50 * N_ORACLE
+        key = lambda h: np.sort(np.rec.fromarrays([h["read"].astype(np.uint64), h["strand"].astype(np.uint64), h["kpos"].astype(np.uint64),
+                                                   h["cmer_index"].astype(np.uint64), h["hd"].astype(np.uint64), h["se"].astype(np.uint64)]))
+        assert (key(gh) == key(rh)).all(), "table hits differ from the oracle"
+        acc = ref["accs"][ref["accs"]["passed"] == 1]
+        want = sorted(zip(acc["read"].tolist(), ((acc["se"] << 1) | acc["strand"]).tolist(), [tuple(x[:5]) for x in acc["hist"].tolist()]))
+        got = sorted(zip(res.rec_read.tolist(), res.rec_key.tolist(), [tuple(x) for x in res.rec_hist.tolist()]))
+        assert got == want, "histograms differ from the oracle"
+        assert_rows_close(res.rows(), rows_of_oracle(ref), tol=1e-6)
+        assert len(res.rows()) > 20 * N_ORACLE
+        st.close()
+        ox.close()
+
+        # ---- 1,000,000 reads (one bench.py step): size-independent properties ----
+        n = N_FULL
+        bases, offs = make_reads(synth, genomes, n, seed=5)
+        stf = dx.stream(max_reads=n, max_bases=len(bases), max_records=n * 64)
+
+        def run(b, o):
+            stf.submit(b, o)
+            r = stf.collect()
+            sel = r.rec_sel.astype(bool)
+            # (read, se, DIST bits) of the output rows as one sortable array
+            return np.stack([r.rec_read[sel].astype(np.uint64), (r.rec_key[sel] >> 1).astype(np.uint64), r.rec_d[sel].view(np.uint64)], axis=1)
+
+        def canon(a):
+            return a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+
+        rows = canon(run(bases, offs))
+        assert len(rows) > 20 * n
+        rc = synth.COMP[bases.reshape(n, 150)[:, ::-1]].reshape(-1)
+        assert (canon(run(rc, offs)) == rows).all(), "reverse-complemented reads give different rows"
+        perm = np.random.default_rng(1).permutation(n)
+        rp = run(bases.reshape(n, 150)[perm].reshape(-1), offs)
+        rp[:, 0] = perm[rp[:, 0].astype(np.int64)].astype(np.uint64)
+        assert (canon(rp) == rows).all(), "permuted reads give different rows"
+        half = n // 2
+        r1 = run(bases[: half * 150], offs[: half + 1])
+        r2 = run(bases[half * 150:], offs[half:] - offs[half])
+        r2[:, 0] += np.uint64(half)
+        assert (canon(np.concatenate([r1, r2])) == rows).all(), "splitting the batch changes the rows"
+        stf.close()
+    finally:
+        dx.close()
+        hx.close()
+        torch.cuda.empty_cache()
