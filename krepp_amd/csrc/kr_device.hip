@@ -451,6 +451,8 @@ struct kr_stream {
   // state
   uint64_t h_rec_cap = 0; // pinned record buffers grow on demand in kr_batch_collect
   bool submitted = false, waited = false;
+  int batch_rc = 0; // result of the batch, returned by every wait / collect until the next submit (errors are sticky)
+  std::string batch_msg;
   uint32_t nreads = 0, flags = 0, nrecs = 0;
   uint32_t scan_blocks = 0;
   uint64_t nhits = 0;
@@ -638,12 +640,16 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
   kr::clear_error();
   if (!s || !bases || !offsets) return kr::fail(KR_ERR_ARG, "kr_batch_submit: null argument");
   if (nreads == 0 || nreads > s->max_reads) return kr::fail(KR_ERR_ARG, "kr_batch_submit: nreads out of range for this stream");
+  // every argument is checked before the stream's state is touched: a rejected submit leaves the previous batch as it was
+  if (!(flags & KR_BASES_DEVICE) && offsets[nreads] > s->max_bases)
+    return kr::fail(KR_ERR_ARG, "kr_batch_submit: more bases than the stream was created for");
   HIP_TRY(hipSetDevice(s->ix->device));
   if (s->submitted && !s->waited) HIP_TRY(hipStreamSynchronize(s->stream));
   s->nreads = nreads;
   s->flags = flags;
   s->submitted = true;
   s->waited = false;
+  s->batch_rc = KR_OK;
   hipStream_t st = s->stream;
   HIP_TRY(hipEventRecord(s->ev[0], st));
   if (flags & KR_BASES_DEVICE) {
@@ -651,7 +657,6 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
     s->in.offsets = offsets;
   } else {
     uint64_t nb = offsets[nreads];
-    if (nb > s->max_bases) return kr::fail(KR_ERR_ARG, "kr_batch_submit: more bases than the stream was created for");
     memcpy(s->h_bases, bases, nb);
     memcpy(s->h_offsets, offsets, ((uint64_t)nreads + 1) * 8);
     HIP_TRY(hipMemcpyAsync(s->d_bases, s->h_bases, nb, hipMemcpyHostToDevice, st));
@@ -765,7 +770,7 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
 int kr_batch_wait(kr_stream* s)
 {
   if (!s || !s->submitted) return kr::fail(KR_ERR_STATE, "kr_batch_wait: nothing submitted");
-  if (s->waited) return KR_OK;
+  if (s->waited) return s->batch_rc ? kr::fail(s->batch_rc, s->batch_msg) : KR_OK;
   HIP_TRY(hipSetDevice(s->ix->device));
   HIP_TRY(hipMemcpyAsync(s->h_counters, s->out.counters, 128, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -780,8 +785,11 @@ int kr_batch_wait(kr_stream* s)
   s->nrecs = std::min(s->h_counters[0], s->rec_cap);
   s->nhits = std::min<uint64_t>(s->h_counters[3], s->hit_cap);
   if (s->h_counters[4] > s->rec_user_cap)
-    return kr::fail(KR_ERR_CAPACITY, "the batch produced more records than max_records: submit fewer reads per batch");
-  return check_errflags(s->h_counters[1]);
+    s->batch_rc = kr::fail(KR_ERR_CAPACITY, "the batch produced more records than max_records: submit fewer reads per batch");
+  else
+    s->batch_rc = check_errflags(s->h_counters[1]);
+  if (s->batch_rc) s->batch_msg = kr_last_error();
+  return s->batch_rc;
 }
 
 static void fill_view(kr_stream* s, kr_result_view* v, bool device)

@@ -911,7 +911,7 @@ struct BgzfSource {
     size_t cap = 0, len = 0;
     unsigned char* ensure(size_t n)
     {
-      if (n > cap) p.reset(new unsigned char[n + n / 4 + 64]), cap = n + n / 4 + 64;
+      if (n > cap || !p) p.reset(new unsigned char[n + n / 4 + 64]), cap = n + n / 4 + 64; // never NULL: zlib rejects a NULL next_out even for an empty member
       len = n;
       return p.get();
     }
@@ -966,9 +966,11 @@ struct BgzfSource {
     while (p < in_len) {
       const uint32_t ms = member_size(in + p, in_len - p);
       if (ms < 28 || p + ms > in_len) return;
+      const uint32_t xl = in[p + 10] | (in[p + 11] << 8);
+      if (12ull + xl + 8 > ms) return; // the extra field claims more than the member holds: no room for a payload and a trailer
       const unsigned char* t = in + p + ms - 4;
       const uint32_t isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
-      if (isize > (1u << 24)) return; // BGZF members inflate to at most 64 KB: a trailer that claims more is damage
+      if (isize > 65536u) return; // BGZF members inflate to at most 64 KB: a trailer that claims more is damage
       mem.push_back({p, ms, total});
       total += isize;
       p += ms;
@@ -1005,7 +1007,11 @@ struct BgzfSource {
         r = todo.front();
         todo.pop_front();
       }
-      inflate_run(*r, zs);
+      try {
+        inflate_run(*r, zs);
+      } catch (const std::bad_alloc&) { // a run that cannot be held is a failed run (reported as a damaged file), not std::terminate
+        r->ok = false;
+      }
       {
         std::lock_guard<std::mutex> lk(mu);
         r->ready = true;

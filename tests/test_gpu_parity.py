@@ -253,6 +253,19 @@ def test_overflow_path_many_leaves(capi, po, synth, tmp_path, monkeypatch, slot_
     with pytest.raises(capi.KrError) as e:
         st2.collect()
     assert e.value.code == capi.KR_ERR_CAPACITY
+    # ... and keeps saying so: a second collect / wait of the same batch is the same error, never truncated records
+    for again in (st2.collect, st2.wait, st2.collect_device):
+        with pytest.raises(capi.KrError) as e:
+            again()
+        assert e.value.code == capi.KR_ERR_CAPACITY
+    # a submit that is rejected for its arguments leaves the stream's previous batch untouched
+    st3 = dx.stream(max_reads=400, max_bases=len(bases), max_records=400 * 2 * n)
+    st3.submit(bases, offs)
+    first = st3.collect().rows()
+    with pytest.raises(capi.KrError) as e:
+        st3.submit(np.concatenate([bases, bases]), np.concatenate([offs, offs[1:] + offs[-1]])[: len(offs)] * 2)  # > max_bases
+    assert e.value.code == capi.KR_ERR_ARG
+    assert st3.collect().rows() == first
 
 
 @pytest.mark.parametrize("dbg", ["0", "2048", "8"])

@@ -247,6 +247,57 @@ def test_block_gzipped_input_is_inflated_in_parallel(capi, tmp_path):
         os.environ.pop("KR_FASTX_THREADS", None)
 
 
+def test_block_gzipped_edge_cases(capi, tmp_path):
+    """(1) the 1 MB run cut lands exactly before the empty EOF member, so a fresh run holds nothing but it: a valid
+    file, not a damaged one; (2) a member whose extra field claims more bytes than the member has, and (3) a trailer
+    that claims more than 64 KB, are errors (no over-read, no giant allocation)."""
+    import struct
+    rng = np.random.default_rng(3)
+    recs, size = [], 0
+    while size < 18 * 60000:
+        n = int(rng.integers(100, 200))
+        rec = b"@q%d\n" % len(recs) + rng.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes() + b"\n+\n" + b"I" * n + b"\n"
+        recs.append(rec)
+        size += len(rec)
+    data = b"".join(recs)
+    # stored (level 0) members of 60,000 bytes: 17 of them stay below 1 MB, the 18th crosses it and ends the run
+    data = data[: 18 * 60000 - 200] + b"@last\n" + b"A" * 90 + b"\n+\n" + b"I" * 90 + b"\n"
+    data = data + b"\n" * (18 * 60000 - len(data))
+    assert len(data) == 18 * 60000
+    bg = tmp_path / "edge.fq.gz"
+    raw = _bgzf_bytes(data, block=60000, level=0)
+    assert len(raw) - 28 >= (1 << 20) and len(raw) - 28 - (len(raw) - 28) // 18 < (1 << 20)
+    bg.write_bytes(raw)
+    plain = tmp_path / "edge.fq"
+    plain.write_bytes(data)
+    os.environ["KR_FASTX_PAR_MIN"] = "0"
+    try:
+        want = capi.read_fastx(str(plain), min_bases=50000)
+        for threads in ("16", "2"):
+            os.environ["KR_FASTX_THREADS"] = threads
+            got = capi.read_fastx(str(bg), min_bases=50000)
+            assert got[0] == want[0] and np.array_equal(got[1], want[1]) and got[0][-1] == "last"
+        os.environ["KR_FASTX_THREADS"] = "2"
+        good = _bgzf_bytes(b"@a\nACGT\n+\nIIII\n")
+        # (2) xlen = 28 in a 40-byte member: 12 + 28 + 8 > 40
+        evil = b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 28) + b"BC" + struct.pack("<HH", 2, 39) + b"XX" + struct.pack("<H", 18) + b"\x00" * 18
+        assert len(evil) == 40
+        f2 = tmp_path / "evil_xlen.fq.gz"
+        f2.write_bytes(good[:-28] + evil + good[-28:])
+        with pytest.raises(capi.KrError):
+            capi.read_fastx(str(f2), min_bases=50000)
+        # (3) a trailer that claims 16 MB
+        m = bytearray(good[:-28])
+        m[-4:] = struct.pack("<I", 1 << 24)
+        f3 = tmp_path / "evil_isize.fq.gz"
+        f3.write_bytes(bytes(m) + good[-28:])
+        with pytest.raises(capi.KrError):
+            capi.read_fastx(str(f3), min_bases=50000)
+    finally:
+        os.environ.pop("KR_FASTX_PAR_MIN", None)
+        os.environ.pop("KR_FASTX_THREADS", None)
+
+
 def test_builder_output_is_consistent_with_brute_force(capi, po, synth, tmp_path):
     """Independent check of the CPU builder: recompute, in pure Python, the minimizers of tiny
     genomes (src/rqseq.cpp:51-144 semantics) and the genome set of every indexed k-mer, and
