@@ -129,6 +129,15 @@ KR_API int kr_index_import(const void* desc, uint64_t desc_bytes, int device, kr
                            uint32_t* nbufs);
 KR_API uint64_t kr_index_device_bytes(const kr_index*);
 
+/* Replicate an uploaded index into the HBM of `ndev` more devices of this node by RCCL broadcast
+ * (ncclBroadcast per flat buffer, one communicator over the root's device and the targets, xGMI):
+ * the index crosses PCIe once, whatever the number of GPUs.  Load time only; there is no collective
+ * on the query path.  Replaces what the reference does once per process, TargetIndex::load_index
+ * (src/krepp.cpp:92-106), for the GPUs after the first.  replicas[i] lives on devices[i] and is freed
+ * with kr_index_free; devices are distinct; a device equal to the root's gives a second copy in the
+ * same HBM (one-rank communicator).  RCCL (librccl.so.1) is loaded on first use. */
+KR_API int kr_index_broadcast(const kr_index* root, int ndev, const int* devices, kr_index** replicas);
+
 /* ------------------------------------------------------------------------- */
 /* Query: IBatch ctor + IBatch::estimate_distances (src/query.cpp:8-38,        */
 /* 141-156): search_mers (:40-94), IMers::add_matching_mer (:352-390),         */

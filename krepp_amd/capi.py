@@ -84,7 +84,7 @@ class KrBuildParams(C.Structure):
 EXPORTS = [
     "kr_host_index_load", "kr_host_sketch_load", "kr_format_seek", "kr_build_sketch", "kr_host_index_free", "kr_host_index_view", "kr_host_index_node_name",
     "kr_host_index_node_label", "kr_host_index_node_parent", "kr_host_index_node_blen",
-    "kr_index_upload", "kr_index_free", "kr_index_export", "kr_index_import", "kr_index_device_bytes",
+    "kr_index_upload", "kr_index_free", "kr_index_export", "kr_index_import", "kr_index_device_bytes", "kr_index_broadcast",
     "kr_params_default", "kr_stream_create", "kr_stream_destroy", "kr_batch_submit", "kr_batch_wait",
     "kr_batch_collect", "kr_batch_collect_device", "kr_batch_hits", "kr_batch_readtaps",
     "kr_debug_front_end", "kr_debug_brent", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
@@ -133,6 +133,7 @@ def load():
     lib.kr_index_export.argtypes = [vp, vp, u64p, C.POINTER(KrIndexBuffer), u32p]
     lib.kr_index_import.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(vp), C.POINTER(KrIndexBuffer), u32p]
     lib.kr_index_device_bytes.argtypes = [vp]
+    lib.kr_index_broadcast.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     lib.kr_index_device_bytes.restype = C.c_uint64
     lib.kr_params_default.argtypes = [C.POINTER(KrParams)]
     lib.kr_params_default.restype = None
@@ -287,6 +288,14 @@ class DeviceIndex:
         bufs = (KrIndexBuffer * 256)()
         check(lib.kr_index_import(desc, len(desc), int(device), C.byref(h), bufs, C.byref(n)))
         return cls(h), [(bufs[i].dptr, bufs[i].bytes) for i in range(n.value)]
+
+    def broadcast(self, devices):
+        """Replicas of this index on `devices`, filled by RCCL broadcast (kr_index_broadcast)."""
+        n = len(devices)
+        devs = (C.c_int * n)(*[int(d) for d in devices])
+        outs = (C.c_void_p * n)()
+        check(self.lib.kr_index_broadcast(self.h, n, devs, outs))
+        return [DeviceIndex(C.c_void_p(outs[i])) for i in range(n)]
 
     @property
     def device_bytes(self):

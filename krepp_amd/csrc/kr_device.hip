@@ -42,6 +42,8 @@
 //   kr_dev_debug.inc       debug / tap kernels and the re-layout kernels of kr_index_upload
 // and, in this file, the host side: kr_index_upload / export / import, kr_stream_*, kr_batch_*, kr_llh_batch.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <type_traits>
 
 #include "kr_common.h"
@@ -416,6 +418,131 @@ int kr_index_import(const void* desc, uint64_t desc_bytes, int device, kr_index*
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------
+// kr_index_broadcast: replicas over RCCL (xGMI), load time only
+// ---------------------------------------------------------------------------
+namespace {
+
+// RCCL is loaded on first use: a process that never replicates an index (every single-GPU run, every rank of a
+// one-process-per-GPU job that replicates through its own transport) neither maps nor initialises it.
+struct Rccl {
+  void* h = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string err;
+  bool load()
+  {
+    if (h) return true;
+    const char* names[] = {getenv("KR_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names)
+      if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) {
+      err = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "librccl.so.1 not found");
+      return false;
+    }
+#define KR_SYM(field, name)                                                            \
+  if (!(field = reinterpret_cast<decltype(field)>(dlsym(h, name)))) {                  \
+    err = std::string("RCCL lacks ") + name;                                           \
+    dlclose(h), h = nullptr;                                                           \
+    return false;                                                                      \
+  }
+    KR_SYM(CommInitAll, "ncclCommInitAll")
+    KR_SYM(CommDestroy, "ncclCommDestroy")
+    KR_SYM(Broadcast, "ncclBroadcast")
+    KR_SYM(GroupStart, "ncclGroupStart")
+    KR_SYM(GroupEnd, "ncclGroupEnd")
+    KR_SYM(GetErrorString, "ncclGetErrorString")
+#undef KR_SYM
+    return true;
+  }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+} // namespace
+
+extern "C" int kr_index_broadcast(const kr_index* root, int ndev, const int* devices, kr_index** replicas)
+{
+  kr::clear_error();
+  if (!root || ndev < 0 || (ndev && (!devices || !replicas))) return kr::fail(KR_ERR_ARG, "kr_index_broadcast: bad argument");
+  if (ndev == 0) return KR_OK;
+  int have = 0;
+  if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return kr::fail(KR_ERR_NO_DEVICE, "no HIP device available");
+  for (int i = 0; i < ndev; ++i) {
+    replicas[i] = nullptr;
+    if (devices[i] < 0 || devices[i] >= have) return kr::fail(KR_ERR_ARG, "kr_index_broadcast: bad device ordinal");
+    for (int j = 0; j < i; ++j)
+      if (devices[j] == devices[i]) return kr::fail(KR_ERR_ARG, "kr_index_broadcast: a device is listed twice");
+  }
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (!g_rccl.load()) return kr::fail(KR_ERR_NO_DEVICE, g_rccl.err);
+  Rccl& R = g_rccl;
+  auto cleanup = [&](int rc) {
+    for (int i = 0; i < ndev; ++i)
+      if (replicas[i]) kr_index_free(replicas[i]), replicas[i] = nullptr;
+    return rc;
+  };
+  // same buffers, same order, on every target device (kr_index_import's allocation)
+  std::vector<std::vector<kr_index_buffer>> rb(ndev);
+  for (int i = 0; i < ndev; ++i) {
+    uint32_t nb = 0;
+    rb[i].resize(root->bufs.size());
+    nb = (uint32_t)rb[i].size();
+    int rc = kr_index_import(root->desc.data(), root->desc.size(), devices[i], &replicas[i], rb[i].data(), &nb);
+    if (rc) return cleanup(rc);
+    if (nb != root->bufs.size()) return cleanup(kr::fail(KR_ERR_FORMAT, "kr_index_broadcast: replica layout differs from the root's"));
+  }
+  // one communicator over {root device} + the target devices that are not the root's; a target ON the root's device
+  // (a second replica in the same HBM: tests, A/B runs) is served by a one-rank communicator, whose out-of-place
+  // broadcast is a device copy
+  std::vector<int> devlist{root->device};
+  std::vector<int> rank_of(ndev, -1);
+  for (int i = 0; i < ndev; ++i)
+    if (devices[i] != root->device) rank_of[i] = (int)devlist.size(), devlist.push_back(devices[i]);
+  const int nranks = (int)devlist.size();
+  std::vector<ncclComm_t> comm(nranks, nullptr);
+  std::vector<hipStream_t> strm(nranks, nullptr);
+  auto nccl_fail = [&](ncclResult_t r, const char* what) {
+    return kr::fail(KR_ERR_NO_DEVICE, std::string(what) + ": " + R.GetErrorString(r));
+  };
+  int rc = KR_OK;
+  ncclResult_t nr = R.CommInitAll(comm.data(), nranks, devlist.data());
+  if (nr != ncclSuccess) return cleanup(nccl_fail(nr, "ncclCommInitAll"));
+  for (int r = 0; r < nranks && rc == KR_OK; ++r) {
+    if (hipSetDevice(devlist[r]) != hipSuccess || hipStreamCreateWithFlags(&strm[r], hipStreamNonBlocking) != hipSuccess)
+      rc = kr::fail(KR_ERR_NO_DEVICE, "kr_index_broadcast: cannot create a stream");
+  }
+  // few, large buffers: one ring broadcast each (per-link bound over xGMI), all ranks of one buffer in one group
+  for (size_t b = 0; b < root->bufs.size() && rc == KR_OK; ++b) {
+    const uint64_t bytes = root->bufs[b].bytes;
+    if (!bytes) continue;
+    if ((nr = R.GroupStart()) != ncclSuccess) { rc = nccl_fail(nr, "ncclGroupStart"); break; }
+    // rank 0 = the root: in place unless a same-device replica wants the bytes too
+    void* root_recv = root->bufs[b].dptr;
+    for (int i = 0; i < ndev; ++i)
+      if (rank_of[i] < 0) root_recv = rb[i][b].dptr; // (at most one: devices are distinct)
+    nr = R.Broadcast(root->bufs[b].dptr, root_recv, bytes, ncclUint8, 0, comm[0], strm[0]);
+    for (int i = 0; i < ndev && nr == ncclSuccess; ++i)
+      if (rank_of[i] > 0) nr = R.Broadcast(rb[i][b].dptr, rb[i][b].dptr, bytes, ncclUint8, 0, comm[rank_of[i]], strm[rank_of[i]]);
+    ncclResult_t ge = R.GroupEnd();
+    if (nr != ncclSuccess || ge != ncclSuccess) rc = nccl_fail(nr != ncclSuccess ? nr : ge, "ncclBroadcast");
+  }
+  for (int r = 0; r < nranks; ++r) {
+    if (!strm[r]) continue;
+    (void)hipSetDevice(devlist[r]);
+    if (hipStreamSynchronize(strm[r]) != hipSuccess && rc == KR_OK) rc = kr::fail(KR_ERR_NO_DEVICE, "kr_index_broadcast: stream failed");
+    (void)hipStreamDestroy(strm[r]);
+  }
+  for (auto c : comm)
+    if (c) (void)R.CommDestroy(c);
+  (void)hipSetDevice(root->device);
+  return rc == KR_OK ? KR_OK : cleanup(rc);
+}
 
 // ---------------------------------------------------------------------------
 // kr_stream

@@ -209,9 +209,14 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
     }
     view.node_kind = kr_place_tree_kinds(ptree); // leaves absent from the placement tree become null nodes
   }
+  // the index crosses PCIe once; the other GPUs receive it by RCCL broadcast over xGMI (load time only)
   std::vector<kr_index*> dix(ngpus, nullptr);
-  for (int g = 0; g < ngpus; ++g)
-    if (kr_index_upload(&view, dev0 + g, KR_VIEW_HOST, &dix[g])) error_exit(kr_last_error());
+  if (kr_index_upload(&view, dev0, KR_VIEW_HOST, &dix[0])) error_exit(kr_last_error());
+  if (ngpus > 1) {
+    std::vector<int> devs;
+    for (int g = 1; g < ngpus; ++g) devs.push_back(dev0 + g);
+    if (kr_index_broadcast(dix[0], ngpus - 1, devs.data(), dix.data() + 1)) error_exit(kr_last_error());
+  }
   if (seek) fprintf(stderr, "Seeking query sequences in the sketch...\n");
   if (!place && !seek) fprintf(stderr, "Estimating distances between given sequences and references...\n");
   auto t0 = std::chrono::steady_clock::now();

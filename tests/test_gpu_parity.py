@@ -491,6 +491,26 @@ def test_index_export_import_roundtrip(capi, toy, toy_reads):
     assert a.rows() == b.rows() and len(a.rows()) > 100
 
 
+def test_index_broadcast_rccl(capi, toy, toy_reads):
+    """kr_index_broadcast: the replica is filled by ncclBroadcast (RCCL, loaded on first use).  One GPU here, so the
+    target is the root's own device (one-rank communicator); N>1 differs only in the communicator's size."""
+    hx, dx, ox = toy
+    names, bases, offs = toy_reads
+    (rep,) = dx.broadcast([0])
+    assert rep.device_bytes == dx.device_bytes
+    _, a = gpu_dist(capi, dx, bases, offs)
+    _, b = gpu_dist(capi, rep, bases, offs)
+    assert a.rows() == b.rows() and len(a.rows()) > 100
+    rep.close()
+    _, c = gpu_dist(capi, dx, bases, offs)  # the root is unharmed by the replica's death
+    assert c.rows() == a.rows()
+    for bad in ([0, 0], [99], [-1]):
+        with pytest.raises(capi.KrError) as e:
+            dx.broadcast(bad)
+        assert e.value.code == capi.KR_ERR_ARG
+    assert dx.broadcast([]) == []
+
+
 def test_export_import_of_a_slotted_index(capi, po, synth, tmp_path, monkeypatch):
     """A dense table carries a slotted copy of its bucket heads: the replica must receive it too."""
     import torch
