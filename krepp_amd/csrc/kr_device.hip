@@ -549,6 +549,7 @@ extern "C" int kr_index_broadcast(const kr_index* root, int ndev, const int* dev
 // ---------------------------------------------------------------------------
 struct kr_stream {
   const kr_index* ix = nullptr;
+  int device = 0; // copy of ix->device: destroying a stream must not read an index that may already be gone
   kr_params params;
   DevParams dp;
   LlhConst llh;
@@ -633,6 +634,7 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   HIP_TRY(hipSetDevice(ix->device));
   std::unique_ptr<kr_stream> s(new kr_stream());
   s->ix = ix;
+  s->device = ix->device;
   s->params = *p;
   s->dp.th = p->hdist_th, s->dp.np = p->hdist_th + 1;
   s->dp.multi = p->multi, s->dp.no_filter = p->no_filter;
@@ -752,7 +754,7 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
 void kr_stream_destroy(kr_stream* s)
 {
   if (!s) return;
-  if (s->ix) (void)hipSetDevice(s->ix->device);
+  (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   for (void* p : s->dallocs) (void)hipFree(p);
   for (void* p : s->hallocs) (void)hipHostFree(p);
@@ -771,6 +773,7 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
   if (!(flags & KR_BASES_DEVICE) && offsets[nreads] > s->max_bases)
     return kr::fail(KR_ERR_ARG, "kr_batch_submit: more bases than the stream was created for");
   HIP_TRY(hipSetDevice(s->ix->device));
+  (void)hipGetLastError(); // a stale error of an earlier, unrelated call on this thread is not this batch's
   if (s->submitted && !s->waited) HIP_TRY(hipStreamSynchronize(s->stream));
   s->nreads = nreads;
   s->flags = flags;

@@ -110,6 +110,23 @@ def test_hip_minimizers_bit_exact(capi, synth, k, w, h, m, r, frac):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,w,h", [(21, 27, 7), (21, 21, 7), (21, 60, 7)])
+def test_hip_minimizers_match_ring_buffer_simulation_directly(capi, k, w, h):
+    """The HIP kernel against the independent pure-Python ring-buffer simulation itself (not through the product's
+    CPU leaf stage): minimizer key sets bit-exact, HyperLogLog sums equal — including the stale-slot emission at the
+    end of a contig whose last run of valid bases is shorter than w (src/rqseq.cpp:108-116)."""
+    rng = np.random.default_rng(5)
+    contigs = make_contigs(rng)
+    contigs.append("".join("ACGT"[i] for i in rng.integers(0, 4, 9000)))  # crosses several 2048-position tiles
+    bases = np.frombuffer("".join(contigs).encode(), np.uint8)
+    offs = np.cumsum([0] + [len(c) for c in contigs]).astype(np.uint64)
+    keys, n1, n2 = capi.minimizers(bases, offs, k, w, h, PPOS, device=0)
+    want, sk = ring_buffer_sim(contigs, k, w, 4, 1, True, PPOS, NPOS)
+    assert keys.tolist() == want.tolist() and len(want) > 100
+    assert n1 == sum(hll12(a) for a, _ in sk) and n2 == sum(hll12(b) for _, b in sk)
+
+
+@pytest.mark.gpu
 def test_index_built_with_gpu_leaf_stage_is_identical(capi, synth, tmp_path):
     import os, time
     nwk = "((a:0.03,b:0.03):0.02,(c:0.05,(d:0.01,e:0.01):0.02):0.01);"
