@@ -170,12 +170,23 @@ KR_API void kr_stream_destroy(kr_stream*);
 #define KR_BASES_HOST 0u
 #define KR_BASES_DEVICE 1u /* bases/offsets already resident in this device's HBM */
 #define KR_TAP_ACCS 2u     /* keep per-(read,strand,leaf) histograms for kr_batch_taps */
-#define KR_TAP_HITS 4u     /* record every table hit (debug; slow)                 */
+#define KR_TAP_HITS 4u     /* record every table hit (debug; slow; the batch runs as one lane) */
+#define KR_BASES_PINNED 8u /* host `bases` are page-locked (hipHostMalloc / hipHostRegister, e.g.  */
+                           /* kr_host_alloc): copied to the device straight from the caller's buffer, */
+                           /* which must stay valid until the batch has been waited for              */
+#define KR_ROWS_ONLY 16u   /* kr_batch_collect brings back only what the `dist` report needs         */
+                           /* (read_off/cnt/na, rec_key/sel/d); rec_v, rec_chisq, rec_hist and        */
+                           /* read_onmers of the host view are then NULL / undefined                  */
 
 /* Queue one batch: `bases` = concatenated ASCII sequences exactly as the FASTX
  * reader delivers them (QSeq::read_next_batch, src/rqseq.cpp:180-197),
  * offsets[nreads+1] = start of each read.  Asynchronous: host buffers must stay
- * valid until kr_batch_collect / kr_batch_wait returns. */
+ * valid until kr_batch_collect / kr_batch_wait returns.
+ *
+ * This replaces the reference's batching (src/rqseq.cpp:180-197 + the task loop src/krepp.cpp:360-387) by
+ * pinned-host staging + hipMemcpyAsync: a batch of >= 2 * 65,536 reads is cut into up to KR_LANES (env, default 4)
+ * contiguous read ranges, each with its own HIP stream: the H2D copy, the kernels and (in kr_batch_collect) the
+ * D2H copy of one range overlap with those of the others.  Results do not depend on the number of lanes. */
 KR_API int kr_batch_submit(kr_stream*, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads,
                            uint32_t flags);
 KR_API int kr_batch_wait(kr_stream*);
@@ -253,6 +264,8 @@ typedef struct kr_timing {
   float ms_h2d;      /* host->device copies (0 with KR_BASES_DEVICE)                 */
   uint32_t overflow_reads; /* reads that took the global-memory accumulator path     */
   uint32_t stack_spills;   /* times a colour-expansion stack outgrew the LDS (large clades) */
+  uint32_t lanes;          /* read ranges the batch was cut into: with one, ms_scan/acc/llh are the kernels' own  */
+                           /* durations; with several they are sums over lanes that share the chip (> ms_total)   */
 } kr_timing;
 KR_API int kr_batch_timing(kr_stream*, kr_timing* out);
 
@@ -288,6 +301,9 @@ KR_API int kr_format_dist(const kr_host_index*, const kr_result_view*, const cha
 KR_API int kr_format_seek(const kr_host_index*, const kr_index*, const kr_result_view*, uint32_t hdist_th,
                           const char* const* names, char** text, uint64_t* len);
 KR_API void kr_free(void*);
+/* Page-locked host memory for read batches (KR_BASES_PINNED): what a reader fills instead of a std::string. */
+KR_API void* kr_host_alloc(uint64_t bytes);
+KR_API void kr_host_free(void*);
 
 /* ------------------------------------------------------------------------- */
 /* `krepp place`: IBatch::place_sequences / report_placement (src/query.cpp:198-333), */

@@ -19,7 +19,7 @@ KR_OK = 0
 KR_ERR_ARG, KR_ERR_IO, KR_ERR_FORMAT, KR_ERR_NO_DEVICE = -1, -2, -3, -4
 KR_ERR_NOMEM, KR_ERR_CAPACITY, KR_ERR_STATE = -5, -6, -7
 KR_VIEW_HOST, KR_VIEW_DEVICE = 0, 1
-KR_BASES_HOST, KR_BASES_DEVICE, KR_TAP_ACCS, KR_TAP_HITS = 0, 1, 2, 4
+KR_BASES_HOST, KR_BASES_DEVICE, KR_TAP_ACCS, KR_TAP_HITS, KR_BASES_PINNED, KR_ROWS_ONLY = 0, 1, 2, 4, 8, 16
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
@@ -62,7 +62,7 @@ class KrHit(C.Structure):
 
 class KrTiming(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_scan", C.c_float), ("ms_acc", C.c_float), ("ms_llh", C.c_float),
-                ("ms_h2d", C.c_float), ("overflow_reads", C.c_uint32), ("stack_spills", C.c_uint32)]
+                ("ms_h2d", C.c_float), ("overflow_reads", C.c_uint32), ("stack_spills", C.c_uint32), ("lanes", C.c_uint32)]
 
 
 class KrFastxBatch(C.Structure):
@@ -90,7 +90,7 @@ EXPORTS = [
     "kr_debug_front_end", "kr_debug_brent", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
     "kr_place_tree_create", "kr_place_tree_create_lineage", "kr_place_tree_nnodes", "kr_place_summary_add",
     "kr_place_summary_text", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_frame",
-    "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_format_dist", "kr_free",
+    "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_format_dist", "kr_free", "kr_host_alloc", "kr_host_free",
     "kr_build_index", "kr_minimizers_cpu", "kr_minimizers_device", "kr_minimizers_free", "kr_last_error", "kr_version",
 ]
 
@@ -170,6 +170,10 @@ def load():
     lib.kr_format_dist.argtypes = [vp, C.POINTER(KrResultView), C.POINTER(C.c_char_p), C.POINTER(vp), u64p]
     lib.kr_free.argtypes = [vp]
     lib.kr_free.restype = None
+    lib.kr_host_alloc.argtypes = [C.c_uint64]
+    lib.kr_host_alloc.restype = vp
+    lib.kr_host_free.argtypes = [vp]
+    lib.kr_host_free.restype = None
     lib.kr_build_index.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(KrBuildParams)]
     lib.kr_minimizers_cpu.argtypes = [C.POINTER(KrBuildParams), vp, vp, C.c_uint32, C.POINTER(KrMinimizerResult)]
     lib.kr_minimizers_device.argtypes = [C.c_int, C.POINTER(KrBuildParams), vp, vp, C.c_uint32, C.POINTER(KrMinimizerResult)]

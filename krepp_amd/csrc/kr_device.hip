@@ -547,28 +547,52 @@ extern "C" int kr_index_broadcast(const kr_index* root, int ndev, const int* dev
 // ---------------------------------------------------------------------------
 // kr_stream
 // ---------------------------------------------------------------------------
+// One batch is cut into up to kMaxLanes contiguous read ranges ("lanes").  A lane is a complete pipeline of its own --
+// HIP stream, H2D copy of its reads, the kernels, its counters -- working on its slice of the stream's result arrays,
+// so that the copies of one lane and the kernels of another overlap, and the three kernel families (scan: HBM request
+// rate; accumulate: latency; likelihood: fp64 ALU) of different lanes can share the chip.  Lanes change nothing in any
+// result: reads are independent, and every lane runs the same kernels on its reads.
+constexpr uint32_t kMaxLanes = 8;
+struct Lane {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  BatchIn in;
+  BatchOut out;                // pointers: the lane's private scratch + its slices of the stream's arrays
+  uint32_t* d_counters = nullptr;
+  uint32_t* d_cursors = nullptr;
+  ulonglong2* d_dd = nullptr;  // private de-duplication table
+  uint32_t dd_slots = 0;
+  uint32_t *d_g_planes = nullptr, *d_g_counts = nullptr, *d_g_list = nullptr;
+  uint64_t* d_stk = nullptr;
+  uint32_t* h_counters = nullptr; // pinned [32]
+  // this batch
+  uint32_t read0 = 0, nreads = 0, rec_base = 0, rec_cap = 0, nrecs = 0;
+  uint64_t host_off = 0;       // where the lane's records start in the compacted host arrays
+};
+
 struct kr_stream {
   const kr_index* ix = nullptr;
   int device = 0; // copy of ix->device: destroying a stream must not read an index that may already be gone
   kr_params params;
   DevParams dp;
   LlhConst llh;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t max_reads = 0;
   uint64_t max_bases = 0;
-  uint32_t rec_cap = 0, hit_cap = 0;
-  uint64_t rec_user_cap = 0; // the caller's max_records (rec_cap adds per-wave chunk slack)
+  uint32_t rec_cap = 0, hit_cap = 0, item_cap = 0;
+  uint64_t rec_user_cap = 0; // the caller's max_records (rec_cap adds per-wave chunk slack per lane)
   uint32_t nwaves = 0, nwaves_full = 0, nwaves_lean = 0; // per-wave scratch slots; grids of the two accumulate launches
-  // device
+  uint32_t max_lanes = 1, nlanes = 1;  // lanes created / lanes of the current batch
+  uint32_t lane_min_reads = 1u << 16;
+  Lane lanes[kMaxLanes];
+  // device: input staging and the result arrays every lane writes its slice of
   uint8_t* d_bases = nullptr;
-  uint64_t* d_offsets = nullptr;
-  BatchOut out;
+  uint64_t* d_offsets = nullptr; // [max_reads + max_lanes]: every lane has its own nreads + 1 entries
+  BatchOut out;                  // the stream-wide arrays (and the constants every lane copies)
   std::vector<void*> dallocs;
   // pinned host
   uint8_t* h_bases = nullptr;
   uint64_t* h_offsets = nullptr;
-  uint32_t* h_counters = nullptr;
+  uint32_t h_counters[32] = {0}; // aggregate of the lanes' counters
   uint32_t *h_rd_off = nullptr, *h_rd_cnt = nullptr, *h_rd_onmers = nullptr, *h_rd_filt = nullptr;
   uint8_t* h_rd_na = nullptr;
   uint32_t *h_rec_key = nullptr, *h_rec_hist = nullptr;
@@ -578,13 +602,13 @@ struct kr_stream {
   std::vector<void*> hallocs;
   // state
   uint64_t h_rec_cap = 0; // pinned record buffers grow on demand in kr_batch_collect
-  bool submitted = false, waited = false;
+  bool h_rec_full = false; // ... and hold v / chisq / hist only once a batch asked for them
+  bool submitted = false, waited = false, collected = false;
   int batch_rc = 0; // result of the batch, returned by every wait / collect until the next submit (errors are sticky)
   std::string batch_msg;
   uint32_t nreads = 0, flags = 0, nrecs = 0;
   uint32_t scan_blocks = 0;
   uint64_t nhits = 0;
-  BatchIn in;
 };
 
 namespace {
@@ -621,209 +645,33 @@ int check_errflags(uint32_t e)
   return KR_OK;
 }
 
-} // namespace
-
-extern "C" {
-
-int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads, uint64_t max_bases, uint64_t max_records,
-                     kr_stream** out)
+// Queue the kernels of one lane on its stream (everything the lane needs is in L.in / L.out).
+int launch_lane(kr_stream* s, Lane& L, uint32_t flags)
 {
-  kr::clear_error();
-  if (!ix || !p || !out || max_reads == 0) return kr::fail(KR_ERR_ARG, "kr_stream_create: bad argument");
-  if (p->hdist_th > KR_MAX_HDIST_TH) return kr::fail(KR_ERR_ARG, "--hdist-th above 16 is not supported (k-h <= 16 bounds hd)");
-  HIP_TRY(hipSetDevice(ix->device));
-  std::unique_ptr<kr_stream> s(new kr_stream());
-  s->ix = ix;
-  s->device = ix->device;
-  s->params = *p;
-  s->dp.th = p->hdist_th, s->dp.np = p->hdist_th + 1;
-  s->dp.multi = p->multi, s->dp.no_filter = p->no_filter;
-  s->dp.dmax_set = std::isnan(p->dist_max) ? 0 : 1;
-  s->dp.dbg = getenv("KR_DEBUG_SKIP") ? (uint32_t)atoi(getenv("KR_DEBUG_SKIP")) : 0u;
-  s->dp.chisq = p->chisq, s->dp.dist_max = p->dist_max;
-  s->llh = make_llh_const(ix->dix.k, ix->dix.h, p->hdist_th);
-  s->max_reads = max_reads, s->max_bases = max_bases;
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
-  // resident waves per CU: LDS-limited (160 KiB per CU), VGPR-limited to 4 waves per SIMD
-  const uint32_t nslots2 = std::max<uint32_t>(2u, 2u * ix->dix.nleaves), bm_words = ((nslots2 + 63) / 64) * 2;
-  // resident accumulate waves per CU: LDS-limited, at most 16 by registers (4 per SIMD); reads are handed out
-  // dynamically, so a grid that is not fully resident costs nothing
-  if (probe_lds_bytes(p->hdist_th + 1, bm_words) > 65536u)
-    return kr::fail(KR_ERR_ARG, "kr_stream_create: this many reference leaves with this --hdist-th needs more LDS than a workgroup has");
-  uint32_t per_cu = std::min<uint32_t>(16u, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words));
-  // the single-segment instantiation has a lean LDS layout and 96 registers: 5 waves per SIMD
-  uint32_t per_cu_lean = std::min<uint32_t>(20u, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words, true));
-  if (getenv("KR_DEBUG_ACC_WAVES")) {
-    per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(getenv("KR_DEBUG_ACC_WAVES")));
-    per_cu_lean = std::min<uint32_t>(per_cu_lean, (uint32_t)atoi(getenv("KR_DEBUG_ACC_WAVES")));
-  }
-  s->nwaves_full = (uint32_t)prop.multiProcessorCount * std::max<uint32_t>(1u, per_cu);
-  s->nwaves_lean = (uint32_t)prop.multiProcessorCount * std::max<uint32_t>(1u, per_cu_lean);
-  { // per-wave global scratch grows with the tree (100 B per leaf for the level-2 tables): bound the total by running
-    // fewer waves on very large trees (reads are handed out dynamically, so any grid size is correct)
-    const uint64_t np_ = p->hdist_th + 1;
-    const uint64_t tab_spill = std::min<uint32_t>(nslots2, 16384u), kt_spill = std::min<uint32_t>(nslots2, 65536u); // as below
-    const uint64_t list_words = std::max<uint64_t>(nslots2, kEvSpill + tab_spill * ((np_ + 3) / 4 + 1) + kt_spill);
-    const uint64_t per_wave = (uint64_t)nslots2 * np_ * (kPlaneWords + 1) * 4 + list_words * 4 + (uint64_t)kStackSpill * 8;
-    const uint64_t budget = (getenv("KR_ACC_SCRATCH_GB") ? (uint64_t)atoi(getenv("KR_ACC_SCRATCH_GB")) : 16ull) << 30;
-    const uint32_t max_waves = (uint32_t)std::max<uint64_t>((uint64_t)prop.multiProcessorCount, budget / per_wave);
-    s->nwaves_full = std::min(s->nwaves_full, max_waves);
-    s->nwaves_lean = std::min(s->nwaves_lean, max_waves);
-  }
-  s->nwaves = std::max(s->nwaves_full, s->nwaves_lean);
-  // default record capacity: up to 2 * leaves per read, at most 16 per read on average
-  uint64_t per_read = std::min<uint64_t>(16, std::max<uint64_t>(8, (uint64_t)ix->dix.tree_nnodes + 1));
-  uint64_t rc64 = max_records ? max_records : std::max<uint64_t>(1u << 16, (uint64_t)max_reads * per_read);
-  s->rec_user_cap = rc64;
-  // every resident wave may leave one partly used chunk behind: add that slack to the caller's bound
-  s->rec_cap = (uint32_t)std::min<uint64_t>(rc64 + (uint64_t)s->nwaves * kRecChunk, 1ull << 30);
-  s->hit_cap = 1u << 22;
-  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
-  int rc = 0;
-  BatchOut& o = s->out;
-  memset(&o, 0, sizeof(o));
-  uint32_t np = s->dp.np;
-#define SA(ptr, n) \
-  if ((rc = salloc(s.get(), &ptr, (n)))) { kr_stream_destroy(s.release()); return rc; }
-#define HA(ptr, n) \
-  if ((rc = halloc(s.get(), &ptr, (n)))) { kr_stream_destroy(s.release()); return rc; }
-  SA(s->d_bases, max_bases + 256);
-  SA(s->d_offsets, (uint64_t)max_reads + 1);
-  SA(o.counters, 32);
-  SA(o.cursors, 3 * kCursors * kCursorStride);
-  SA(o.rd_off, max_reads);
-  SA(o.rd_cnt, max_reads);
-  SA(o.rd_onmers, max_reads);
-  SA(o.rd_filt, 2ull * max_reads);
-  SA(o.rd_na, max_reads);
-  SA(o.rec_read, s->rec_cap);
-  SA(o.rec_key, s->rec_cap);
-  SA(o.rec_hist, (uint64_t)s->rec_cap * np);
-  SA(o.rec_d, s->rec_cap);
-  SA(o.rec_v, s->rec_cap);
-  SA(o.rec_chisq, s->rec_cap);
-  SA(o.rec_sel, s->rec_cap);
-  SA(o.rec_w0, s->rec_cap);
-  SA(o.rec_rep, s->rec_cap);
-  SA(o.rep_list, s->rec_cap);
-  SA(o.rep_dv, s->rec_cap);
-  o.dd_shift = getenv("KR_DD_SHIFT") ? (uint32_t)atoi(getenv("KR_DD_SHIFT")) : 1u; // measured: 1: 5.1 ms, 3: 5.6, 5: 6.9 (llh + select, syn1000)
-  o.dd_slots = std::min<uint32_t>(next_pow2(std::max<uint32_t>(2048u, s->rec_cap >> o.dd_shift)), 1u << 26);
-  SA(o.dd_table, o.dd_slots);
-  o.rec_cap = s->rec_cap;
-  o.hit_cap = s->hit_cap;
-  // item list between the two kernels: 256 hits per read on average, plus one partly used chunk per scan wave
-  s->scan_blocks = (uint32_t)prop.multiProcessorCount * (4u * (ix->slot_log2w ? KR_SCAN_WPE_SLOT : KR_SCAN_WPE) / kScanWaves); // resident by construction (launch bounds)
-  o.item_cap = (uint32_t)std::min<uint64_t>((uint64_t)max_reads * 256u + (uint64_t)s->scan_blocks * kScanWaves * 2u * kItemChunk, 1ull << 31);
-  SA(o.items, o.item_cap);
-  SA(o.rd_it_off, max_reads);
-  SA(o.rd_it_cnt, max_reads);
-  SA(o.long_list, (uint64_t)max_reads + 16ull * s->nwaves);
-  SA(o.stk_spill, (uint64_t)s->nwaves * kStackSpill);
-  o.nslots2 = nslots2;
-  o.ev_spill = kEvSpill;
-  o.tab_spill = std::min<uint32_t>(nslots2, 16384u);
-  o.kt_spill = std::min<uint32_t>(nslots2, 65536u);
-  const uint32_t g_list_words = std::max<uint32_t>(nslots2, o.ev_spill + o.tab_spill * ((np + 3) / 4 + 1) + o.kt_spill);
-  o.g_list_words = g_list_words;
-  o.bm_words = bm_words;
-  SA(o.g_planes, (uint64_t)s->nwaves * nslots2 * np * kPlaneWords);
-  SA(o.g_counts, (uint64_t)s->nwaves * nslots2 * np);
-  SA(o.g_list, (uint64_t)s->nwaves * g_list_words);
-  // on the stream's own stream and waited for: the stream does not synchronise with the null stream, and a
-  // multi-GB clear (large trees) would otherwise still be running when the first batch arrives
-  HIP_TRY(hipMemsetAsync(o.g_planes, 0, (uint64_t)s->nwaves * nslots2 * np * kPlaneWords * 4, s->stream));
-  HIP_TRY(hipMemsetAsync(o.g_counts, 0, (uint64_t)s->nwaves * nslots2 * np * 4, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  HA(s->h_bases, max_bases + 256);
-  HA(s->h_offsets, (uint64_t)max_reads + 1);
-  HA(s->h_counters, 32);
-  HA(s->h_rd_off, max_reads);
-  HA(s->h_rd_cnt, max_reads);
-  HA(s->h_rd_onmers, max_reads);
-  HA(s->h_rd_filt, 2ull * max_reads);
-  HA(s->h_rd_na, max_reads);
-#undef SA
-#undef HA
-  *out = s.release();
-  return KR_OK;
-}
-
-void kr_stream_destroy(kr_stream* s)
-{
-  if (!s) return;
-  (void)hipSetDevice(s->device);
-  if (s->stream) (void)hipStreamSynchronize(s->stream);
-  for (void* p : s->dallocs) (void)hipFree(p);
-  for (void* p : s->hallocs) (void)hipHostFree(p);
-  for (auto& e : s->ev)
-    if (e) (void)hipEventDestroy(e);
-  if (s->stream) (void)hipStreamDestroy(s->stream);
-  delete s;
-}
-
-int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads, uint32_t flags)
-{
-  kr::clear_error();
-  if (!s || !bases || !offsets) return kr::fail(KR_ERR_ARG, "kr_batch_submit: null argument");
-  if (nreads == 0 || nreads > s->max_reads) return kr::fail(KR_ERR_ARG, "kr_batch_submit: nreads out of range for this stream");
-  // every argument is checked before the stream's state is touched: a rejected submit leaves the previous batch as it was
-  if (!(flags & KR_BASES_DEVICE) && offsets[nreads] > s->max_bases)
-    return kr::fail(KR_ERR_ARG, "kr_batch_submit: more bases than the stream was created for");
-  HIP_TRY(hipSetDevice(s->ix->device));
-  (void)hipGetLastError(); // a stale error of an earlier, unrelated call on this thread is not this batch's
-  if (s->submitted && !s->waited) HIP_TRY(hipStreamSynchronize(s->stream));
-  s->nreads = nreads;
-  s->flags = flags;
-  s->submitted = true;
-  s->waited = false;
-  s->batch_rc = KR_OK;
-  hipStream_t st = s->stream;
-  HIP_TRY(hipEventRecord(s->ev[0], st));
-  if (flags & KR_BASES_DEVICE) {
-    s->in.bases = bases;
-    s->in.offsets = offsets;
-  } else {
-    uint64_t nb = offsets[nreads];
-    memcpy(s->h_bases, bases, nb);
-    memcpy(s->h_offsets, offsets, ((uint64_t)nreads + 1) * 8);
-    HIP_TRY(hipMemcpyAsync(s->d_bases, s->h_bases, nb, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->d_offsets, s->h_offsets, ((uint64_t)nreads + 1) * 8, hipMemcpyHostToDevice, st));
-    s->in.bases = s->d_bases;
-    s->in.offsets = s->d_offsets;
-  }
-  s->in.nreads = nreads;
+  hipStream_t st = L.stream;
+  const uint32_t nreads = L.nreads;
+  BatchOut& o = L.out;
   { // about four chunks' worth of reads per wave, between 32 and kRecChunk slots (one shared counter serves ~90 M atomics/s:
     // a million-read batch must not take its slots 32 at a time)
     uint32_t per_wave = (uint32_t)std::min<uint64_t>(4ull * nreads / std::max<uint32_t>(1u, s->nwaves_lean), kRecChunk), c = 32;
     while (c < per_wave) c <<= 1;
-    s->out.rec_chunk = std::min<uint32_t>(c, kRecChunk);
+    o.rec_chunk = std::min<uint32_t>(c, kRecChunk);
   }
-  HIP_TRY(hipMemsetAsync(s->out.counters, 0, 128, st));
-  HIP_TRY(hipMemsetAsync(s->out.cursors, 0, 3 * kCursors * kCursorStride * 4, st));
-  HIP_TRY(hipMemsetAsync(s->out.rec_key, 0, (uint64_t)s->rec_cap * 4, st));
-  HIP_TRY(hipMemsetAsync(s->out.rec_sel, 0, (uint64_t)s->rec_cap, st));
-  HIP_TRY(hipEventRecord(s->ev[1], st));
+  HIP_TRY(hipMemsetAsync(o.counters, 0, 128, st));
+  HIP_TRY(hipMemsetAsync(o.cursors, 0, 3 * kCursors * kCursorStride * 4, st));
+  HIP_TRY(hipMemsetAsync(o.rec_key, 0, (uint64_t)o.rec_cap * 4, st));
+  HIP_TRY(hipMemsetAsync(o.rec_sel, 0, (uint64_t)o.rec_cap, st));
+  HIP_TRY(hipEventRecord(L.ev[1], st));
   const DevIndex& dix = s->ix->dix;
-  if (flags & KR_TAP_HITS) {
-    if (!s->h_hits) {
-      HIP_TRY(hipMalloc((void**)&s->out.hits, (uint64_t)s->hit_cap * sizeof(kr_hit)));
-      s->dallocs.push_back(s->out.hits);
-      HIP_TRY(hipHostMalloc((void**)&s->h_hits, (uint64_t)s->hit_cap * sizeof(kr_hit), hipHostMallocDefault));
-      s->hallocs.push_back(s->h_hits);
-    }
-  }
   {
     const bool tap = (flags & KR_TAP_HITS) != 0;
     const uint32_t sgrid = std::min<uint32_t>((nreads + kScanWaves - 1) / kScanWaves, s->scan_blocks);
 #define KR_LAUNCH2(LG, CP, SLV, SLT)                                                                                          \
   do {                                                                                                                   \
     if (tap)                                                                                                             \
-      hipLaunchKernelGGL((kr_scan_kernel_t<LG, CP, SLV, true, SLT>), dim3(sgrid), dim3(kScanWaves* kWave), 0, st, dix, s->dp, s->in, s->out); \
+      hipLaunchKernelGGL((kr_scan_kernel_t<LG, CP, SLV, true, SLT>), dim3(sgrid), dim3(kScanWaves* kWave), 0, st, dix, s->dp, L.in, o); \
     else                                                                                                                 \
-      hipLaunchKernelGGL((kr_scan_kernel_t<LG, CP, SLV, false, SLT>), dim3(sgrid), dim3(kScanWaves* kWave), 0, st, dix, s->dp, s->in, s->out); \
+      hipLaunchKernelGGL((kr_scan_kernel_t<LG, CP, SLV, false, SLT>), dim3(sgrid), dim3(kScanWaves* kWave), 0, st, dix, s->dp, L.in, o); \
   } while (0)
 #define KR_LAUNCH(LG, CP, SLT)          \
   do {                                  \
@@ -846,14 +694,14 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
     }
 #undef KR_LAUNCH2
 #undef KR_LAUNCH
-    HIP_TRY(hipEventRecord(s->ev[2], st));
-    const uint32_t lds = probe_lds_bytes(s->dp.np, s->out.bm_words), lds_lean = probe_lds_bytes(s->dp.np, s->out.bm_words, true);
+    HIP_TRY(hipEventRecord(L.ev[2], st));
+    const uint32_t lds = probe_lds_bytes(s->dp.np, o.bm_words), lds_lean = probe_lds_bytes(s->dp.np, o.bm_words, true);
     const uint32_t grid_lean = std::min(nreads, s->nwaves_lean), grid_full = std::min(nreads, s->nwaves_full);
     const bool np5 = s->dp.np == 5 && !getenv("KR_DEBUG_NP0");
 #define KR_ACC(SLV, NPV)                                                                                                       \
   do {                                                                                                                       \
-    hipLaunchKernelGGL((kr_acc_kernel_t<SLV, NPV, false>), dim3(grid_lean), dim3(kWave), lds_lean, st, dix, s->dp, s->in, s->out); \
-    hipLaunchKernelGGL((kr_acc_kernel_t<SLV, NPV, true>), dim3(grid_full), dim3(kWave), lds, st, dix, s->dp, s->in, s->out);  \
+    hipLaunchKernelGGL((kr_acc_kernel_t<SLV, NPV, false>), dim3(grid_lean), dim3(kWave), lds_lean, st, dix, s->dp, L.in, o); \
+    hipLaunchKernelGGL((kr_acc_kernel_t<SLV, NPV, true>), dim3(grid_full), dim3(kWave), lds, st, dix, s->dp, L.in, o);  \
   } while (0)
     if (single && np5)
       KR_ACC(true, 5);
@@ -865,35 +713,276 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
       KR_ACC(false, 0);
 #undef KR_ACC
   }
-  HIP_TRY(hipEventRecord(s->ev[3], st));
-  hipLaunchKernelGGL(kr_dedup_clear_kernel, dim3(4096), dim3(256), 0, st, s->out);
+  HIP_TRY(hipEventRecord(L.ev[3], st));
+  hipLaunchKernelGGL(kr_dedup_clear_kernel, dim3(4096), dim3(256), 0, st, o);
   if (s->llh.th == 4) {
-    hipLaunchKernelGGL(kr_dedup_kernel, dim3(4096), dim3(256), 0, st, s->out);
-    hipLaunchKernelGGL(kr_llh_pre_kernel<5>, dim3(4096), dim3(256), 0, st, s->llh, dix, s->out);
-    hipLaunchKernelGGL(kr_llh_kernel<5>, dim3(2048), dim3(256), 0, st, s->llh, dix, s->out);
+    hipLaunchKernelGGL(kr_dedup_kernel, dim3(4096), dim3(256), 0, st, o);
+    hipLaunchKernelGGL(kr_llh_pre_kernel<5>, dim3(4096), dim3(256), 0, st, s->llh, dix, o);
+    hipLaunchKernelGGL(kr_llh_kernel<5>, dim3(2048), dim3(256), 0, st, s->llh, dix, o);
   } else {
-    hipLaunchKernelGGL(kr_dedup_kernel, dim3(4096), dim3(256), 0, st, s->out);
-    hipLaunchKernelGGL(kr_llh_pre_kernel<0>, dim3(4096), dim3(256), 0, st, s->llh, dix, s->out);
-    hipLaunchKernelGGL(kr_llh_kernel<0>, dim3(2048), dim3(256), 0, st, s->llh, dix, s->out);
+    hipLaunchKernelGGL(kr_dedup_kernel, dim3(4096), dim3(256), 0, st, o);
+    hipLaunchKernelGGL(kr_llh_pre_kernel<0>, dim3(4096), dim3(256), 0, st, s->llh, dix, o);
+    hipLaunchKernelGGL(kr_llh_kernel<0>, dim3(2048), dim3(256), 0, st, s->llh, dix, o);
   }
-  hipLaunchKernelGGL(kr_llh_copy_kernel, dim3(4096), dim3(256), 0, st, s->out);
+  hipLaunchKernelGGL(kr_llh_copy_kernel, dim3(4096), dim3(256), 0, st, o);
   {
     const uint32_t sgrid = std::min<uint32_t>((nreads + 7) / 8, 16384u);
     const bool filt = !s->dp.no_filter && s->dp.multi;
     if (s->llh.th == 4) {
       if (filt)
-        hipLaunchKernelGGL((kr_select_kernel<5, true>), dim3(sgrid), dim3(256), 0, st, s->llh, dix, s->dp, s->out, nreads);
+        hipLaunchKernelGGL((kr_select_kernel<5, true>), dim3(sgrid), dim3(256), 0, st, s->llh, dix, s->dp, o, nreads);
       else
-        hipLaunchKernelGGL((kr_select_kernel<5, false>), dim3(sgrid), dim3(256), 0, st, s->llh, dix, s->dp, s->out, nreads);
+        hipLaunchKernelGGL((kr_select_kernel<5, false>), dim3(sgrid), dim3(256), 0, st, s->llh, dix, s->dp, o, nreads);
     } else {
       if (filt)
-        hipLaunchKernelGGL((kr_select_kernel<0, true>), dim3(sgrid), dim3(256), 0, st, s->llh, dix, s->dp, s->out, nreads);
+        hipLaunchKernelGGL((kr_select_kernel<0, true>), dim3(sgrid), dim3(256), 0, st, s->llh, dix, s->dp, o, nreads);
       else
-        hipLaunchKernelGGL((kr_select_kernel<0, false>), dim3(sgrid), dim3(256), 0, st, s->llh, dix, s->dp, s->out, nreads);
+        hipLaunchKernelGGL((kr_select_kernel<0, false>), dim3(sgrid), dim3(256), 0, st, s->llh, dix, s->dp, o, nreads);
     }
   }
-  HIP_TRY(hipEventRecord(s->ev[4], st));
+  if (L.rec_base) // the result view indexes the stream's arrays, the lane's kernels its slice
+    hipLaunchKernelGGL(kr_rebase_kernel, dim3(std::min<uint32_t>((nreads + 255) / 256, 1024u)), dim3(256), 0, st, o.rd_off, o.rd_cnt, nreads, L.rec_base);
+  HIP_TRY(hipEventRecord(L.ev[4], st));
+  HIP_TRY(hipMemcpyAsync(L.h_counters, o.counters, 128, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipGetLastError());
+  return KR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads, uint64_t max_bases, uint64_t max_records,
+                     kr_stream** out)
+{
+  kr::clear_error();
+  if (!ix || !p || !out || max_reads == 0) return kr::fail(KR_ERR_ARG, "kr_stream_create: bad argument");
+  if (p->hdist_th > KR_MAX_HDIST_TH) return kr::fail(KR_ERR_ARG, "--hdist-th above 16 is not supported (k-h <= 16 bounds hd)");
+  HIP_TRY(hipSetDevice(ix->device));
+  std::unique_ptr<kr_stream> s(new kr_stream());
+  s->ix = ix;
+  s->device = ix->device;
+  s->params = *p;
+  s->dp.th = p->hdist_th, s->dp.np = p->hdist_th + 1;
+  s->dp.multi = p->multi, s->dp.no_filter = p->no_filter;
+  s->dp.dmax_set = std::isnan(p->dist_max) ? 0 : 1;
+  s->dp.dbg = getenv("KR_DEBUG_SKIP") ? (uint32_t)atoi(getenv("KR_DEBUG_SKIP")) : 0u;
+  s->dp.chisq = p->chisq, s->dp.dist_max = p->dist_max;
+  s->llh = make_llh_const(ix->dix.k, ix->dix.h, p->hdist_th);
+  s->max_reads = max_reads, s->max_bases = max_bases;
+  // lanes: batches of at least 2 * lane_min_reads reads are cut into up to KR_LANES ranges (default 4)
+  if (const char* e = getenv("KR_LANE_MIN_READS")) s->lane_min_reads = (uint32_t)std::max(1, atoi(e));
+  {
+    uint32_t want = getenv("KR_LANES") ? (uint32_t)std::max(1, atoi(getenv("KR_LANES"))) : 4u;
+    s->max_lanes = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(want, kMaxLanes), max_reads / s->lane_min_reads));
+  }
+  const uint32_t ML = s->max_lanes;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
+  // resident waves per CU: LDS-limited (160 KiB per CU), VGPR-limited to 4 waves per SIMD
+  const uint32_t nslots2 = std::max<uint32_t>(2u, 2u * ix->dix.nleaves), bm_words = ((nslots2 + 63) / 64) * 2;
+  // resident accumulate waves per CU: LDS-limited, at most 16 by registers (4 per SIMD); reads are handed out
+  // dynamically, so a grid that is not fully resident costs nothing
+  if (probe_lds_bytes(p->hdist_th + 1, bm_words) > 65536u)
+    return kr::fail(KR_ERR_ARG, "kr_stream_create: this many reference leaves with this --hdist-th needs more LDS than a workgroup has");
+  uint32_t per_cu = std::min<uint32_t>(16u, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words));
+  // the single-segment instantiation has a lean LDS layout and 96 registers: 5 waves per SIMD
+  uint32_t per_cu_lean = std::min<uint32_t>(20u, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words, true));
+  if (getenv("KR_DEBUG_ACC_WAVES")) {
+    per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(getenv("KR_DEBUG_ACC_WAVES")));
+    per_cu_lean = std::min<uint32_t>(per_cu_lean, (uint32_t)atoi(getenv("KR_DEBUG_ACC_WAVES")));
+  }
+  s->nwaves_full = (uint32_t)prop.multiProcessorCount * std::max<uint32_t>(1u, per_cu);
+  s->nwaves_lean = (uint32_t)prop.multiProcessorCount * std::max<uint32_t>(1u, per_cu_lean);
+  const uint32_t np = s->dp.np;
+  { // per-wave global scratch grows with the tree (100 B per leaf for the level-2 tables): bound the total by running
+    // fewer waves on very large trees (reads are handed out dynamically, so any grid size is correct)
+    const uint64_t np_ = np;
+    const uint64_t tab_spill = std::min<uint32_t>(nslots2, 16384u), kt_spill = std::min<uint32_t>(nslots2, 65536u); // as below
+    const uint64_t list_words = std::max<uint64_t>(nslots2, kEvSpill + tab_spill * ((np_ + 3) / 4 + 1) + kt_spill);
+    const uint64_t per_wave = (uint64_t)nslots2 * np_ * (kPlaneWords + 1) * 4 + list_words * 4 + (uint64_t)kStackSpill * 8;
+    const uint64_t budget = ((getenv("KR_ACC_SCRATCH_GB") ? (uint64_t)atoi(getenv("KR_ACC_SCRATCH_GB")) : 16ull) << 30) / ML;
+    const uint32_t max_waves = (uint32_t)std::max<uint64_t>((uint64_t)prop.multiProcessorCount, budget / per_wave);
+    s->nwaves_full = std::min(s->nwaves_full, max_waves);
+    s->nwaves_lean = std::min(s->nwaves_lean, max_waves);
+  }
+  s->nwaves = std::max(s->nwaves_full, s->nwaves_lean);
+  // default record capacity: up to 2 * leaves per read, at most 16 per read on average
+  uint64_t per_read = std::min<uint64_t>(16, std::max<uint64_t>(8, (uint64_t)ix->dix.tree_nnodes + 1));
+  uint64_t rc64 = max_records ? max_records : std::max<uint64_t>(1u << 16, (uint64_t)max_reads * per_read);
+  s->rec_user_cap = rc64;
+  // every resident wave of every lane may leave one partly used chunk behind: add that slack to the caller's bound
+  s->rec_cap = (uint32_t)std::min<uint64_t>(rc64 + (uint64_t)ML * s->nwaves * kRecChunk, 1ull << 30);
+  s->hit_cap = 1u << 22;
+  int rc = 0;
+  BatchOut& o = s->out;
+  memset(&o, 0, sizeof(o));
+#define SA(ptr, n) \
+  if ((rc = salloc(s.get(), &ptr, (n)))) { kr_stream_destroy(s.release()); return rc; }
+#define HA(ptr, n) \
+  if ((rc = halloc(s.get(), &ptr, (n)))) { kr_stream_destroy(s.release()); return rc; }
+  SA(s->d_bases, max_bases + 256);
+  SA(s->d_offsets, (uint64_t)max_reads + ML);
+  SA(o.rd_off, max_reads);
+  SA(o.rd_cnt, max_reads);
+  SA(o.rd_onmers, max_reads);
+  SA(o.rd_filt, 2ull * max_reads);
+  SA(o.rd_na, max_reads);
+  SA(o.rec_read, s->rec_cap);
+  SA(o.rec_key, s->rec_cap);
+  SA(o.rec_hist, (uint64_t)s->rec_cap * np);
+  SA(o.rec_d, s->rec_cap);
+  SA(o.rec_v, s->rec_cap);
+  SA(o.rec_chisq, s->rec_cap);
+  SA(o.rec_sel, s->rec_cap);
+  SA(o.rec_w0, s->rec_cap);
+  SA(o.rec_rep, s->rec_cap);
+  SA(o.rep_list, s->rec_cap);
+  SA(o.rep_dv, s->rec_cap);
+  o.dd_shift = getenv("KR_DD_SHIFT") ? (uint32_t)atoi(getenv("KR_DD_SHIFT")) : 1u; // measured: 1: 5.1 ms, 3: 5.6, 5: 6.9 (llh + select, syn1000)
+  o.rec_cap = s->rec_cap;
+  o.rec_stride = s->rec_cap;
+  o.hit_cap = s->hit_cap;
+  // item list between the two kernels: 256 hits per read on average, plus one partly used chunk per scan wave of every lane
+  s->scan_blocks = (uint32_t)prop.multiProcessorCount * (4u * (ix->slot_log2w ? KR_SCAN_WPE_SLOT : KR_SCAN_WPE) / kScanWaves); // resident by construction (launch bounds)
+  if (const char* e = getenv("KR_DEBUG_SCAN_BLOCKS_PER_CU")) s->scan_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)std::max(1, atoi(e));
+  s->item_cap = (uint32_t)std::min<uint64_t>((uint64_t)max_reads * 256u + (uint64_t)ML * s->scan_blocks * kScanWaves * 2u * kItemChunk, 1ull << 31);
+  SA(o.items, s->item_cap);
+  SA(o.rd_it_off, max_reads);
+  SA(o.rd_it_cnt, max_reads);
+  SA(o.long_list, (uint64_t)max_reads + 16ull * s->nwaves * ML);
+  o.nslots2 = nslots2;
+  o.ev_spill = kEvSpill;
+  o.tab_spill = std::min<uint32_t>(nslots2, 16384u);
+  o.kt_spill = std::min<uint32_t>(nslots2, 65536u);
+  const uint32_t g_list_words = std::max<uint32_t>(nslots2, o.ev_spill + o.tab_spill * ((np + 3) / 4 + 1) + o.kt_spill);
+  o.g_list_words = g_list_words;
+  o.bm_words = bm_words;
+  for (uint32_t l = 0; l < ML; ++l) {
+    Lane& L = s->lanes[l];
+    HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    for (auto& e : L.ev) HIP_TRY(hipEventCreate(&e));
+    SA(L.d_counters, 32);
+    SA(L.d_cursors, 3 * kCursors * kCursorStride);
+    // lane 0 may be the only lane of a batch; a later lane never holds more than half of one
+    const uint32_t lane_recs = l == 0 ? s->rec_cap : s->rec_cap / 2;
+    L.dd_slots = std::min<uint32_t>(next_pow2(std::max<uint32_t>(2048u, lane_recs >> o.dd_shift)), 1u << 26);
+    SA(L.d_dd, L.dd_slots);
+    SA(L.d_stk, (uint64_t)s->nwaves * kStackSpill);
+    SA(L.d_g_planes, (uint64_t)s->nwaves * nslots2 * np * kPlaneWords);
+    SA(L.d_g_counts, (uint64_t)s->nwaves * nslots2 * np);
+    SA(L.d_g_list, (uint64_t)s->nwaves * g_list_words);
+    // on the lane's own stream and waited for: it does not synchronise with the null stream, and a
+    // multi-GB clear (large trees) would otherwise still be running when the first batch arrives
+    HIP_TRY(hipMemsetAsync(L.d_g_planes, 0, (uint64_t)s->nwaves * nslots2 * np * kPlaneWords * 4, L.stream));
+    HIP_TRY(hipMemsetAsync(L.d_g_counts, 0, (uint64_t)s->nwaves * nslots2 * np * 4, L.stream));
+    HA(L.h_counters, 32);
+  }
+  for (uint32_t l = 0; l < ML; ++l) HIP_TRY(hipStreamSynchronize(s->lanes[l].stream));
+  HA(s->h_bases, max_bases + 256);
+  HA(s->h_offsets, (uint64_t)max_reads + 1);
+  HA(s->h_rd_off, max_reads);
+  HA(s->h_rd_cnt, max_reads);
+  HA(s->h_rd_onmers, max_reads);
+  HA(s->h_rd_filt, 2ull * max_reads);
+  HA(s->h_rd_na, max_reads);
+#undef SA
+#undef HA
+  *out = s.release();
+  return KR_OK;
+}
+
+void kr_stream_destroy(kr_stream* s)
+{
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  for (auto& L : s->lanes)
+    if (L.stream) (void)hipStreamSynchronize(L.stream);
+  for (void* p : s->dallocs) (void)hipFree(p);
+  for (void* p : s->hallocs) (void)hipHostFree(p);
+  for (auto& L : s->lanes) {
+    for (auto& e : L.ev)
+      if (e) (void)hipEventDestroy(e);
+    if (L.stream) (void)hipStreamDestroy(L.stream);
+  }
+  delete s;
+}
+
+int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads, uint32_t flags)
+{
+  kr::clear_error();
+  if (!s || !bases || !offsets) return kr::fail(KR_ERR_ARG, "kr_batch_submit: null argument");
+  if (nreads == 0 || nreads > s->max_reads) return kr::fail(KR_ERR_ARG, "kr_batch_submit: nreads out of range for this stream");
+  // every argument is checked before the stream's state is touched: a rejected submit leaves the previous batch as it was
+  if (!(flags & KR_BASES_DEVICE) && offsets[nreads] - offsets[0] > s->max_bases)
+    return kr::fail(KR_ERR_ARG, "kr_batch_submit: more bases than the stream was created for");
+  HIP_TRY(hipSetDevice(s->ix->device));
+  (void)hipGetLastError(); // a stale error of an earlier, unrelated call on this thread is not this batch's
+  if (s->submitted && !s->waited)
+    for (uint32_t l = 0; l < s->nlanes; ++l) HIP_TRY(hipStreamSynchronize(s->lanes[l].stream));
+  s->nreads = nreads;
+  s->flags = flags;
+  s->submitted = true;
+  s->waited = false;
+  s->collected = false;
+  s->batch_rc = KR_OK;
+  // lanes of this batch: ranges of at least lane_min_reads reads; the hit tap (tests) keeps one hit buffer, hence one lane
+  uint32_t P = std::min<uint32_t>(s->max_lanes, std::max<uint32_t>(1u, nreads / s->lane_min_reads));
+  if (flags & KR_TAP_HITS) P = 1;
+  s->nlanes = P;
+  if (flags & KR_TAP_HITS) {
+    if (!s->h_hits) {
+      HIP_TRY(hipMalloc((void**)&s->out.hits, (uint64_t)s->hit_cap * sizeof(kr_hit)));
+      s->dallocs.push_back(s->out.hits);
+      HIP_TRY(hipHostMalloc((void**)&s->h_hits, (uint64_t)s->hit_cap * sizeof(kr_hit), hipHostMallocDefault));
+      s->hallocs.push_back(s->h_hits);
+    }
+  }
+  const uint32_t lane_rec_cap = P == 1 ? s->rec_cap : (s->rec_cap / P) & ~63u;
+  const uint32_t lane_item_cap = s->item_cap / P;
+  for (uint32_t l = 0; l < P; ++l) {
+    Lane& L = s->lanes[l];
+    const uint32_t r0 = (uint32_t)((uint64_t)nreads * l / P), r1 = (uint32_t)((uint64_t)nreads * (l + 1) / P);
+    L.read0 = r0, L.nreads = r1 - r0, L.rec_base = l * lane_rec_cap, L.rec_cap = lane_rec_cap, L.nrecs = 0;
+    hipStream_t st = L.stream;
+    HIP_TRY(hipEventRecord(L.ev[0], st));
+    if (flags & KR_BASES_DEVICE) {
+      L.in.bases = bases;
+      L.in.offsets = offsets + r0;
+    } else {
+      // the lane's bases land at the same offsets in d_bases as in the caller's buffer (relative to offsets[0]); its
+      // offsets are rebased to the staging buffer
+      const uint64_t b0 = offsets[r0] - offsets[0], b1 = offsets[r1] - offsets[0];
+      uint64_t* ho = s->h_offsets; // [nreads + 1], shared boundary entries are written with the same value
+      const uint8_t* src = bases + offsets[r0];
+      if (!(flags & KR_BASES_PINNED)) {
+        memcpy(s->h_bases + b0, src, b1 - b0);
+        src = s->h_bases + b0;
+      }
+      for (uint32_t r = r0; r <= r1; ++r) ho[r] = offsets[r] - offsets[0];
+      HIP_TRY(hipMemcpyAsync(s->d_bases + b0, src, b1 - b0, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(s->d_offsets + r0 + l, ho + r0, ((uint64_t)(r1 - r0) + 1) * 8, hipMemcpyHostToDevice, st));
+      L.in.bases = s->d_bases;
+      L.in.offsets = s->d_offsets + r0 + l;
+    }
+    L.in.nreads = r1 - r0;
+    // the lane's view of the output: private scratch + slices of the stream's arrays
+    BatchOut& o = L.out;
+    o = s->out;
+    o.counters = L.d_counters, o.cursors = L.d_cursors;
+    o.dd_table = L.d_dd, o.dd_slots = L.dd_slots;
+    o.g_planes = L.d_g_planes, o.g_counts = L.d_g_counts, o.g_list = L.d_g_list, o.stk_spill = L.d_stk;
+    o.rd_off += r0, o.rd_cnt += r0, o.rd_onmers += r0, o.rd_filt += 2ull * r0, o.rd_na += r0;
+    o.rd_it_off += r0, o.rd_it_cnt += r0;
+    o.long_list += r0 + 16ull * s->nwaves * l;
+    o.items += (uint64_t)l * lane_item_cap, o.item_cap = lane_item_cap;
+    const uint64_t rb = L.rec_base;
+    o.rec_read += rb, o.rec_key += rb, o.rec_hist += rb, o.rec_d += rb, o.rec_v += rb, o.rec_chisq += rb, o.rec_sel += rb;
+    o.rec_w0 += rb, o.rec_rep += rb, o.rep_list += rb, o.rep_dv += rb;
+    o.rec_cap = lane_rec_cap;
+    int rc = launch_lane(s, L, flags);
+    if (rc) return rc;
+  }
   return KR_OK;
 }
 
@@ -902,8 +991,21 @@ int kr_batch_wait(kr_stream* s)
   if (!s || !s->submitted) return kr::fail(KR_ERR_STATE, "kr_batch_wait: nothing submitted");
   if (s->waited) return s->batch_rc ? kr::fail(s->batch_rc, s->batch_msg) : KR_OK;
   HIP_TRY(hipSetDevice(s->ix->device));
-  HIP_TRY(hipMemcpyAsync(s->h_counters, s->out.counters, 128, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  memset(s->h_counters, 0, sizeof(s->h_counters));
+  uint32_t recs = 0, extent = 0;
+  bool lane_full = false;
+  for (uint32_t l = 0; l < s->nlanes; ++l) {
+    Lane& L = s->lanes[l];
+    HIP_TRY(hipStreamSynchronize(L.stream)); // kernels done, counters in L.h_counters
+    const uint32_t* c = L.h_counters;
+    L.nrecs = std::min(c[0], L.rec_cap);
+    extent = std::max(extent, L.nrecs ? L.rec_base + L.nrecs : 0u);
+    recs += c[4];
+    lane_full = lane_full || c[0] > L.rec_cap;
+    s->h_counters[1] |= c[1];
+    for (int i : {2, 3, 4, 9, 10, 11, 12, 13, 16, 17, 18, 19, 20, 21, 22, 26}) s->h_counters[i] += c[i];
+    for (int i : {14, 15}) s->h_counters[i] = std::max(s->h_counters[i], c[i]);
+  }
   s->waited = true;
   if (s->dp.dbg & 512u)
     fprintf(stderr, "[kr stats] reads %u events %u keys %u batches %u big %u level-tiles %u max keys %u max events %u records %u\n", s->nreads,
@@ -912,12 +1014,12 @@ int kr_batch_wait(kr_stream* s)
   if (s->dp.dbg & 512u)
     fprintf(stderr, "[kr stats] wave cycles/64 per launch: level passes %u (zero %u, event passes %u, key passes %u), finalize %u, whole read %u\n",
             s->h_counters[16], s->h_counters[19], s->h_counters[20], s->h_counters[21], s->h_counters[17], s->h_counters[18]);
-  s->nrecs = std::min(s->h_counters[0], s->rec_cap);
+  s->nrecs = extent; // record slots of the device view, unused ones (rec_key == 0) included
   s->nhits = std::min<uint64_t>(s->h_counters[3], s->hit_cap);
-  if (s->h_counters[4] > s->rec_user_cap)
+  if (recs > s->rec_user_cap)
     s->batch_rc = kr::fail(KR_ERR_CAPACITY, "the batch produced more records than max_records: submit fewer reads per batch");
   else
-    s->batch_rc = check_errflags(s->h_counters[1]);
+    s->batch_rc = check_errflags(s->h_counters[1] | (lane_full ? kErrRecCap : 0u));
   if (s->batch_rc) s->batch_msg = kr_last_error();
   return s->batch_rc;
 }
@@ -927,6 +1029,7 @@ static void fill_view(kr_stream* s, kr_result_view* v, bool device)
   memset(v, 0, sizeof(*v));
   v->nreads = s->nreads;
   v->nrecs = s->nrecs;
+  const bool rows_only = (s->flags & KR_ROWS_ONLY) != 0;
   if (device) {
     v->read_off = s->out.rd_off, v->read_cnt = s->out.rd_cnt, v->read_onmers = s->out.rd_onmers, v->read_na = s->out.rd_na;
     v->rec_key = s->out.rec_key, v->rec_sel = s->out.rec_sel, v->rec_d = s->out.rec_d, v->rec_v = s->out.rec_v;
@@ -934,8 +1037,10 @@ static void fill_view(kr_stream* s, kr_result_view* v, bool device)
     v->rec_hist_stride = s->rec_cap;
   } else {
     v->read_off = s->h_rd_off, v->read_cnt = s->h_rd_cnt, v->read_onmers = s->h_rd_onmers, v->read_na = s->h_rd_na;
-    v->rec_key = s->h_rec_key, v->rec_sel = s->h_rec_sel, v->rec_d = s->h_rec_d, v->rec_v = s->h_rec_v;
-    v->rec_chisq = s->h_rec_chisq, v->rec_hist = (s->flags & KR_TAP_ACCS) ? s->h_rec_hist : nullptr;
+    v->rec_key = s->h_rec_key, v->rec_sel = s->h_rec_sel, v->rec_d = s->h_rec_d;
+    v->rec_v = rows_only ? nullptr : s->h_rec_v;
+    v->rec_chisq = rows_only ? nullptr : s->h_rec_chisq;
+    v->rec_hist = (s->flags & KR_TAP_ACCS) && !rows_only ? s->h_rec_hist : nullptr;
     v->rec_hist_stride = s->nrecs;
   }
 }
@@ -944,12 +1049,16 @@ int kr_batch_collect(kr_stream* s, kr_result_view* v)
 {
   kr::clear_error();
   if (!s || !v) return kr::fail(KR_ERR_ARG, "kr_batch_collect: null argument");
-  int rc = kr_batch_wait(s);
-  if (rc) return rc;
-  hipStream_t st = s->stream;
-  uint64_t nr = s->nreads, nc = s->nrecs;
-  if (nc > s->h_rec_cap) { // (re)allocate pinned record buffers
-    uint64_t cap = std::max<uint64_t>(nc + nc / 4, 1u << 16);
+  if (!s->submitted) return kr::fail(KR_ERR_STATE, "kr_batch_collect: nothing submitted");
+  HIP_TRY(hipSetDevice(s->ix->device));
+  const bool rows_only = (s->flags & KR_ROWS_ONLY) != 0, full = !rows_only;
+  const bool pipelined = !s->waited && !s->collected;
+  // Lane by lane: as soon as a lane's kernels are done its results start their way to the host on the lane's own
+  // stream, while later lanes still compute.  The host arrays are compact (no unused slots between lanes), so a lane's
+  // records land behind those of the lanes before it.
+  auto ensure_host = [&](uint64_t need) -> int {
+    if (need <= s->h_rec_cap && (s->h_rec_full || !full)) return KR_OK;
+    uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(need + need / 4, s->h_rec_cap), 1u << 16);
     void** olds[] = {(void**)&s->h_rec_key, (void**)&s->h_rec_hist, (void**)&s->h_rec_sel, (void**)&s->h_rec_d, (void**)&s->h_rec_v, (void**)&s->h_rec_chisq};
     for (void** o : olds)
       if (*o) {
@@ -957,33 +1066,94 @@ int kr_batch_collect(kr_stream* s, kr_result_view* v)
         (void)hipHostFree(*o);
         *o = nullptr;
       }
+    s->h_rec_cap = 0;
     int rc2 = 0;
-    if ((rc2 = halloc(s, &s->h_rec_key, cap)) || (rc2 = halloc(s, &s->h_rec_hist, cap * s->dp.np)) || (rc2 = halloc(s, &s->h_rec_sel, cap)) ||
-        (rc2 = halloc(s, &s->h_rec_d, cap)) || (rc2 = halloc(s, &s->h_rec_v, cap)) || (rc2 = halloc(s, &s->h_rec_chisq, cap)))
-      return rc2;
+    if ((rc2 = halloc(s, &s->h_rec_key, cap)) || (rc2 = halloc(s, &s->h_rec_sel, cap)) || (rc2 = halloc(s, &s->h_rec_d, cap))) return rc2;
+    s->h_rec_full = s->h_rec_full || full;
+    if (s->h_rec_full)
+      if ((rc2 = halloc(s, &s->h_rec_hist, cap * s->dp.np)) || (rc2 = halloc(s, &s->h_rec_v, cap)) || (rc2 = halloc(s, &s->h_rec_chisq, cap))) return rc2;
     s->h_rec_cap = cap;
+    return KR_OK;
+  };
+  if (!pipelined || s->nlanes == 1 || (s->flags & KR_TAP_ACCS)) {
+    int rc = kr_batch_wait(s); // (the histogram planes are laid out by the total record count: it must be known first)
+    if (rc) return rc;
   }
-  HIP_TRY(hipMemcpyAsync(s->h_rd_off, s->out.rd_off, nr * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(s->h_rd_cnt, s->out.rd_cnt, nr * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(s->h_rd_onmers, s->out.rd_onmers, nr * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(s->h_rd_filt, s->out.rd_filt, nr * 8, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(s->h_rd_na, s->out.rd_na, nr, hipMemcpyDeviceToHost, st));
-  if (nc) {
-    HIP_TRY(hipMemcpyAsync(s->h_rec_key, s->out.rec_key, nc * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(s->h_rec_sel, s->out.rec_sel, nc, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(s->h_rec_d, s->out.rec_d, nc * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(s->h_rec_v, s->out.rec_v, nc * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(s->h_rec_chisq, s->out.rec_chisq, nc * 8, hipMemcpyDeviceToHost, st));
-    if (s->flags & KR_TAP_ACCS)
-      for (uint32_t x = 0; x < s->dp.np; ++x)
-        HIP_TRY(hipMemcpyAsync(s->h_rec_hist + (uint64_t)x * nc, s->out.rec_hist + (uint64_t)x * s->rec_cap, nc * 4, hipMemcpyDeviceToHost, st));
+  uint64_t hoff = 0;
+  bool copies_started = false;
+  if (s->waited) {
+    uint64_t total = 0;
+    for (uint32_t l = 0; l < s->nlanes; ++l) total += s->lanes[l].nrecs;
+    int rc = ensure_host(total);
+    if (rc) return rc;
   }
-  if ((s->flags & KR_TAP_HITS) && s->nhits)
-    HIP_TRY(hipMemcpyAsync(s->h_hits, s->out.hits, s->nhits * sizeof(kr_hit), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  const uint64_t hist_stride_host = [&] { uint64_t t = 0; for (uint32_t l = 0; l < s->nlanes; ++l) t += s->lanes[l].nrecs; return t; }();
+  for (uint32_t l = 0; l < s->nlanes; ++l) {
+    Lane& L = s->lanes[l];
+    hipStream_t st = L.stream;
+    if (!s->waited) {
+      HIP_TRY(hipStreamSynchronize(st));
+      L.nrecs = std::min(L.h_counters[0], L.rec_cap);
+      // room for this lane and, by its measure, for the lanes still running; if not, start over once everything is known
+      const uint64_t guess = hoff + (uint64_t)L.nrecs * (s->nlanes - l) + (uint64_t)L.nrecs / 8 * (s->nlanes - l - 1);
+      if (guess > s->h_rec_cap || (full && !s->h_rec_full)) {
+        for (uint32_t j = 0; j < s->nlanes; ++j) HIP_TRY(hipStreamSynchronize(s->lanes[j].stream));
+        int rc = kr_batch_wait(s);
+        if (rc) return rc;
+        uint64_t total = 0;
+        for (uint32_t j = 0; j < s->nlanes; ++j) total += s->lanes[j].nrecs;
+        if ((rc = ensure_host(total))) return rc;
+        if (copies_started) { // restart: the buffers moved
+          l = (uint32_t)-1, hoff = 0, copies_started = false;
+          continue;
+        }
+      }
+    }
+    L.host_off = hoff;
+    const uint64_t nr = L.nreads, nc = L.nrecs, r0 = L.read0;
+    const BatchOut& o = L.out;
+    HIP_TRY(hipMemcpyAsync(s->h_rd_off + r0, o.rd_off, nr * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(s->h_rd_cnt + r0, o.rd_cnt, nr * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(s->h_rd_na + r0, o.rd_na, nr, hipMemcpyDeviceToHost, st));
+    if (full) {
+      HIP_TRY(hipMemcpyAsync(s->h_rd_onmers + r0, o.rd_onmers, nr * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(s->h_rd_filt + 2 * r0, o.rd_filt, nr * 8, hipMemcpyDeviceToHost, st));
+    }
+    if (nc) {
+      HIP_TRY(hipMemcpyAsync(s->h_rec_key + hoff, o.rec_key, nc * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(s->h_rec_sel + hoff, o.rec_sel, nc, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(s->h_rec_d + hoff, o.rec_d, nc * 8, hipMemcpyDeviceToHost, st));
+      if (full) {
+        HIP_TRY(hipMemcpyAsync(s->h_rec_v + hoff, o.rec_v, nc * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(s->h_rec_chisq + hoff, o.rec_chisq, nc * 8, hipMemcpyDeviceToHost, st));
+        if (s->flags & KR_TAP_ACCS)
+          for (uint32_t x = 0; x < s->dp.np; ++x)
+            HIP_TRY(hipMemcpyAsync(s->h_rec_hist + (uint64_t)x * hist_stride_host + hoff, o.rec_hist + (uint64_t)x * s->rec_cap, nc * 4, hipMemcpyDeviceToHost, st));
+      }
+    }
+    copies_started = true;
+    hoff += nc;
+  }
+  if ((s->flags & KR_TAP_HITS) && s->waited && s->nhits)
+    HIP_TRY(hipMemcpyAsync(s->h_hits, s->out.hits, s->nhits * sizeof(kr_hit), hipMemcpyDeviceToHost, s->lanes[0].stream));
+  int rc = kr_batch_wait(s); // (a no-op when it already ran; otherwise every lane is idle by now: aggregates the counters)
+  for (uint32_t l = 0; l < s->nlanes; ++l) HIP_TRY(hipStreamSynchronize(s->lanes[l].stream));
+  if (rc) return rc;
+  // device offsets index the stream's arrays (lane slices); the host arrays are compact
+  for (uint32_t l = 0; l < s->nlanes; ++l) {
+    const Lane& L = s->lanes[l];
+    const uint32_t delta = (uint32_t)L.host_off - L.rec_base; // (mod 2^32)
+    if (!delta) continue;
+    uint32_t* off = s->h_rd_off + L.read0;
+    const uint32_t* cnt = s->h_rd_cnt + L.read0;
+    for (uint32_t r = 0; r < L.nreads; ++r) off[r] = cnt[r] ? off[r] + delta : 0u;
+  }
+  s->collected = true;
   fill_view(s, v, false);
+  v->nrecs = (uint32_t)hoff;
+  v->rec_hist_stride = hoff;
   uint64_t nrows = 0;
-  for (uint64_t i = 0; i < nc; ++i) nrows += s->h_rec_sel[i];
+  for (uint64_t i = 0; i < hoff; ++i) nrows += s->h_rec_sel[i];
   v->nrows = nrows;
   return KR_OK;
 }
@@ -1017,14 +1187,47 @@ int kr_batch_timing(kr_stream* s, kr_timing* t)
 {
   if (!s || !t || !s->waited) return kr::fail(KR_ERR_STATE, "kr_batch_timing: wait for a batch first");
   memset(t, 0, sizeof(*t));
-  HIP_TRY(hipEventElapsedTime(&t->ms_h2d, s->ev[0], s->ev[1]));
-  HIP_TRY(hipEventElapsedTime(&t->ms_scan, s->ev[1], s->ev[2]));
-  HIP_TRY(hipEventElapsedTime(&t->ms_acc, s->ev[2], s->ev[3]));
-  HIP_TRY(hipEventElapsedTime(&t->ms_llh, s->ev[3], s->ev[4]));
-  HIP_TRY(hipEventElapsedTime(&t->ms_total, s->ev[1], s->ev[4]));
+  // per phase: the sum over the lanes of the time between the lane's events (with one lane: the kernels' own time;
+  // with several, lanes share the chip and the sums exceed ms_total, the span from the first lane's first kernel to the
+  // last lane's last)
+  float first = 0, last = 0;
+  for (uint32_t l = 0; l < s->nlanes; ++l) {
+    Lane& L = s->lanes[l];
+    float a = 0;
+    HIP_TRY(hipEventElapsedTime(&a, L.ev[0], L.ev[1]));
+    t->ms_h2d += a;
+    HIP_TRY(hipEventElapsedTime(&a, L.ev[1], L.ev[2]));
+    t->ms_scan += a;
+    HIP_TRY(hipEventElapsedTime(&a, L.ev[2], L.ev[3]));
+    t->ms_acc += a;
+    HIP_TRY(hipEventElapsedTime(&a, L.ev[3], L.ev[4]));
+    t->ms_llh += a;
+    if (l) {
+      HIP_TRY(hipEventElapsedTime(&a, s->lanes[0].ev[1], L.ev[1]));
+      first = std::min(first, a);
+    }
+    HIP_TRY(hipEventElapsedTime(&a, s->lanes[0].ev[1], L.ev[4]));
+    last = std::max(last, a);
+  }
+  t->ms_total = last - first;
+  t->lanes = s->nlanes;
   t->overflow_reads = s->h_counters[2];
   t->stack_spills = s->h_counters[26];
   return KR_OK;
+}
+
+void* kr_host_alloc(uint64_t bytes)
+{
+  void* p = nullptr;
+  if (hipHostMalloc(&p, std::max<uint64_t>(bytes, 16), hipHostMallocDefault) != hipSuccess) {
+    kr::fail(KR_ERR_NOMEM, "kr_host_alloc: cannot allocate page-locked memory");
+    return nullptr;
+  }
+  return p;
+}
+void kr_host_free(void* p)
+{
+  if (p) (void)hipHostFree(p);
 }
 
 int kr_debug_front_end(const kr_index* ix, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads, uint32_t stride,

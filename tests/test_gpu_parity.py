@@ -468,6 +468,61 @@ def test_large_batch_properties(capi, toy, toy_genomes, synth):
     assert r1.rows() + [(r + half, s, d) for r, s, d in r2.rows()] == rows
 
 
+def test_lanes_do_not_change_results(capi, toy, toy_genomes, synth, monkeypatch):
+    """A batch cut into several lanes (own HIP stream, own H2D/D2H copies, slices of the result arrays) returns what one
+    lane returns: records, histograms, rows, report text; host view, device view, KR_ROWS_ONLY and KR_BASES_PINNED."""
+    import ctypes as C
+    hx, dx, ox = toy
+    bases, offs, names = synth.sample_reads(toy_genomes, 3001, seed=13)
+    st1, one = gpu_dist(capi, dx, bases, offs, capi.KR_TAP_ACCS)
+    assert st1.timing().lanes == 1
+    text1 = st1.format_dist(hx, names)
+    key = lambda r: (r.rec_read.tolist(), r.rec_key.tolist(), r.rec_sel.tolist(), r.rec_d.tolist(), r.rec_v.tolist())
+    monkeypatch.setenv("KR_LANE_MIN_READS", "500")
+    for lanes in ("2", "3", "5"):
+        monkeypatch.setenv("KR_LANES", lanes)
+        st, res = gpu_dist(capi, dx, bases, offs, capi.KR_TAP_ACCS)
+        assert st.timing().lanes == int(lanes)
+        assert key(res) == key(one) and res.rec_hist.tolist() == one.rec_hist.tolist()
+        assert res.read_onmers.tolist() == one.read_onmers.tolist() and res.read_na.tolist() == one.read_na.tolist()
+        assert st.format_dist(hx, names) == text1
+        # the pipelined collect (no histograms: results leave lane by lane), twice in a row on one stream
+        for _ in range(2):
+            st.submit(bases, offs)
+            r2 = st.collect()
+            assert key(r2) == key(one)
+        # rows only + page-locked input
+        nb = len(bases)
+        pin = capi.load().kr_host_alloc(nb)
+        assert pin
+        C.memmove(pin, bases.ctypes.data, nb)
+        pb = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(nb,))
+        st.submit(pb, offs, capi.KR_BASES_PINNED | capi.KR_ROWS_ONLY)
+        r3 = st.collect()
+        assert (r3.rec_read.tolist(), r3.rec_key.tolist(), r3.rec_sel.tolist(), r3.rec_d.tolist()) == key(one)[:4]
+        assert st.format_dist(hx, names) == text1
+        # device view: offsets index the stream's arrays (lane slices)
+        st.submit(bases, offs)
+        rv = st.collect_device()
+        import torch
+
+        class DevPtr:
+            def __init__(self, ptr, nbytes):
+                self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+        def dev(ptr, n, dt):
+            a = torch.as_tensor(DevPtr(C.cast(ptr, C.c_void_p).value, n * np.dtype(dt).itemsize), device="cuda:0").cpu().numpy()
+            return a.view(dt)
+
+        n = rv.nreads
+        off, cnt = dev(rv.read_off, n, np.uint32), dev(rv.read_cnt, n, np.uint32)
+        k_, d_, s_ = dev(rv.rec_key, rv.nrecs, np.uint32), dev(rv.rec_d, rv.nrecs, np.float64), dev(rv.rec_sel, rv.nrecs, np.uint8)
+        got = sorted((r, int(k_[i]) >> 1, float(d_[i])) for r in range(n) for i in range(off[r], off[r] + cnt[r]) if s_[i])
+        assert got == one.rows()
+        capi.load().kr_host_free(pin)
+        st.close()
+
+
 def test_index_export_import_roundtrip(capi, toy, toy_reads):
     """The replication path used for multi-GPU: export flat buffers, import on a device,
     copy the bytes, query the replica."""

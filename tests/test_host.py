@@ -31,7 +31,7 @@ def test_struct_sizes_match_header(capi):
     assert C.sizeof(capi.KrParams) == 32
     assert C.sizeof(capi.KrHit) == 32
     assert C.sizeof(capi.KrResultView) == 8 + 10 * 8 + 8 + 8
-    assert C.sizeof(capi.KrTiming) == 28
+    assert C.sizeof(capi.KrTiming) == 32
 
 
 def test_host_index_matches_oracle_loader(capi, po, toy_index_dir):
