@@ -171,9 +171,9 @@ KR_API void kr_stream_destroy(kr_stream*);
 #define KR_BASES_DEVICE 1u /* bases/offsets already resident in this device's HBM */
 #define KR_TAP_ACCS 2u     /* keep per-(read,strand,leaf) histograms for kr_batch_taps */
 #define KR_TAP_HITS 4u     /* record every table hit (debug; slow; the batch runs as one lane) */
-#define KR_BASES_PINNED 8u /* host `bases` are page-locked (hipHostMalloc / hipHostRegister, e.g.  */
-                           /* kr_host_alloc): copied to the device straight from the caller's buffer, */
-                           /* which must stay valid until the batch has been waited for              */
+#define KR_BASES_PINNED 8u /* host `bases` AND `offsets` are page-locked (hipHostMalloc / hipHostRegister, */
+                           /* e.g. kr_host_alloc): copied to the device straight from the caller's       */
+                           /* buffers, which must stay valid until the batch has been waited for         */
 #define KR_ROWS_ONLY 16u   /* kr_batch_collect brings back only what the `dist` report needs         */
                            /* (read_off/cnt/na, rec_key/sel/d); rec_v, rec_chisq, rec_hist and        */
                            /* read_onmers of the host view are then NULL / undefined                  */
@@ -184,9 +184,10 @@ KR_API void kr_stream_destroy(kr_stream*);
  * valid until kr_batch_collect / kr_batch_wait returns.
  *
  * This replaces the reference's batching (src/rqseq.cpp:180-197 + the task loop src/krepp.cpp:360-387) by
- * pinned-host staging + hipMemcpyAsync: a batch of >= 2 * 65,536 reads is cut into up to KR_LANES (env, default 4)
+ * pinned-host staging + hipMemcpyAsync: a HOST batch of >= 2 * 65,536 reads is cut into up to KR_LANES (env, default 2)
  * contiguous read ranges, each with its own HIP stream: the H2D copy, the kernels and (in kr_batch_collect) the
- * D2H copy of one range overlap with those of the others.  Results do not depend on the number of lanes. */
+ * D2H copy of one range overlap with those of the other.  Results do not depend on the number of lanes.  Across
+ * batches, two kr_streams used in turn overlap one batch's copies with the other's kernels (bench.py, the CLI). */
 KR_API int kr_batch_submit(kr_stream*, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads,
                            uint32_t flags);
 KR_API int kr_batch_wait(kr_stream*);

@@ -358,8 +358,8 @@ class Result:
         self.rec_key = key[keep]
         self.rec_sel = _np(rv.rec_sel, c, np.uint8)[keep]
         self.rec_d = _np(rv.rec_d, c, np.float64)[keep]
-        self.rec_v = _np(rv.rec_v, c, np.float64)[keep]
-        self.rec_chisq = _np(rv.rec_chisq, c, np.float64)[keep]
+        self.rec_v = _np(rv.rec_v, c, np.float64)[keep] if rv.rec_v else None       # NULL with KR_ROWS_ONLY
+        self.rec_chisq = _np(rv.rec_chisq, c, np.float64)[keep] if rv.rec_chisq else None
         self.rec_hist = (_np(rv.rec_hist, c * np_planes, np.uint32).reshape(np_planes, -1).T[keep]
                          if copy_hist and rv.rec_hist and c else (np.zeros((0, np_planes), np.uint32) if copy_hist else None))
         # read index of every record, and offsets into the compacted arrays
@@ -413,6 +413,13 @@ class Stream:
         check(self.lib.kr_batch_collect(self.h, C.byref(rv)))
         self._rv = rv
         return Result(rv, self.params.hdist_th + 1, bool(self._flags & KR_TAP_ACCS))
+
+    def collect_view(self):
+        """kr_batch_collect without building numpy copies: the raw result view (pointers into the stream's pinned buffers)."""
+        rv = KrResultView()
+        check(self.lib.kr_batch_collect(self.h, C.byref(rv)))
+        self._rv = rv
+        return rv
 
     def collect_device(self):
         rv = KrResultView()

@@ -583,6 +583,7 @@ struct kr_stream {
   uint32_t nwaves = 0, nwaves_full = 0, nwaves_lean = 0; // per-wave scratch slots; grids of the two accumulate launches
   uint32_t max_lanes = 1, nlanes = 1;  // lanes created / lanes of the current batch
   uint32_t lane_min_reads = 1u << 16;
+  bool lanes_for_device_input = false;
   Lane lanes[kMaxLanes];
   // device: input staging and the result arrays every lane writes its slice of
   uint8_t* d_bases = nullptr;
@@ -770,10 +771,14 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   s->dp.chisq = p->chisq, s->dp.dist_max = p->dist_max;
   s->llh = make_llh_const(ix->dix.k, ix->dix.h, p->hdist_th);
   s->max_reads = max_reads, s->max_bases = max_bases;
-  // lanes: batches of at least 2 * lane_min_reads reads are cut into up to KR_LANES ranges (default 4)
+  // lanes: host batches of at least 2 * lane_min_reads reads are cut into up to KR_LANES ranges (default 2: the copies of
+  // one range overlap the kernels of the other; more ranges only add launches -- measured on the 10 GB index, reads
+  // resident in HBM: 1 lane 13.3 ms per million reads, 2: 13.9, 4: 14.9, 8: 16.2, whatever share of the chip the
+  // persistent scan / accumulate grids are given: the kernels of different lanes do not speed each other up)
   if (const char* e = getenv("KR_LANE_MIN_READS")) s->lane_min_reads = (uint32_t)std::max(1, atoi(e));
+  s->lanes_for_device_input = getenv("KR_LANES_DEVICE") != nullptr; // experiments: lanes for batches already in HBM too
   {
-    uint32_t want = getenv("KR_LANES") ? (uint32_t)std::max(1, atoi(getenv("KR_LANES"))) : 4u;
+    uint32_t want = getenv("KR_LANES") ? (uint32_t)std::max(1, atoi(getenv("KR_LANES"))) : 2u;
     s->max_lanes = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(want, kMaxLanes), max_reads / s->lane_min_reads));
   }
   const uint32_t ML = s->max_lanes;
@@ -929,6 +934,7 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
   // lanes of this batch: ranges of at least lane_min_reads reads; the hit tap (tests) keeps one hit buffer, hence one lane
   uint32_t P = std::min<uint32_t>(s->max_lanes, std::max<uint32_t>(1u, nreads / s->lane_min_reads));
   if (flags & KR_TAP_HITS) P = 1;
+  if ((flags & KR_BASES_DEVICE) && !s->lanes_for_device_input) P = 1; // nothing to copy, nothing to overlap
   s->nlanes = P;
   if (flags & KR_TAP_HITS) {
     if (!s->h_hits) {
@@ -953,13 +959,16 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
       // the lane's bases land at the same offsets in d_bases as in the caller's buffer (relative to offsets[0]); its
       // offsets are rebased to the staging buffer
       const uint64_t b0 = offsets[r0] - offsets[0], b1 = offsets[r1] - offsets[0];
-      uint64_t* ho = s->h_offsets; // [nreads + 1], shared boundary entries are written with the same value
+      const uint64_t* ho = s->h_offsets; // [nreads + 1], shared boundary entries are written with the same value
       const uint8_t* src = bases + offsets[r0];
       if (!(flags & KR_BASES_PINNED)) {
         memcpy(s->h_bases + b0, src, b1 - b0);
         src = s->h_bases + b0;
       }
-      for (uint32_t r = r0; r <= r1; ++r) ho[r] = offsets[r] - offsets[0];
+      if ((flags & KR_BASES_PINNED) && offsets[0] == 0)
+        ho = offsets; // page-locked and already relative to the staging buffer: no host pass at all
+      else
+        for (uint32_t r = r0; r <= r1; ++r) s->h_offsets[r] = offsets[r] - offsets[0];
       HIP_TRY(hipMemcpyAsync(s->d_bases + b0, src, b1 - b0, hipMemcpyHostToDevice, st));
       HIP_TRY(hipMemcpyAsync(s->d_offsets + r0 + l, ho + r0, ((uint64_t)(r1 - r0) + 1) * 8, hipMemcpyHostToDevice, st));
       L.in.bases = s->d_bases;
@@ -1152,9 +1161,19 @@ int kr_batch_collect(kr_stream* s, kr_result_view* v)
   fill_view(s, v, false);
   v->nrecs = (uint32_t)hoff;
   v->rec_hist_stride = hoff;
-  uint64_t nrows = 0;
-  for (uint64_t i = 0; i < hoff; ++i) nrows += s->h_rec_sel[i];
-  v->nrows = nrows;
+  { // number of output rows: tens of millions of flags for a large batch, summed by the host pool
+    const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::min(kr::parallel_width(), 16), hoff >> 20));
+    std::vector<uint64_t> part((size_t)nt, 0);
+    const uint8_t* sel = s->h_rec_sel;
+    kr::parallel_for(nt, [&](int t) {
+      uint64_t a = hoff * (uint64_t)t / nt, b = hoff * (uint64_t)(t + 1) / nt, c = 0;
+      for (uint64_t i = a; i < b; ++i) c += sel[i];
+      part[(size_t)t] = c;
+    });
+    uint64_t nrows = 0;
+    for (uint64_t c : part) nrows += c;
+    v->nrows = nrows;
+  }
   return KR_OK;
 }
 
