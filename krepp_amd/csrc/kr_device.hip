@@ -122,6 +122,15 @@ struct kr_index {
   uint64_t bytes = 0;
   // workspace of kr_llh_batch (grown on demand, reused across calls): one device buffer and one pinned host
   // buffer laid out [hist n*np | uc n | rho n | d_in n | d_out n | v n]
+  // kernel chain: the kernels of every batch (every lane of every kr_stream) on this index run one batch after the
+  // other, in submission order -- each batch's first kernel waits for the event recorded behind the previous batch's
+  // last -- while the H2D copy in front of them and the D2H copy behind them overlap other batches' kernels.
+  // Concurrent batches only slow each other down (measured), and a pipeline whose stages take turns
+  // keeps the chip busy with two streams.
+  mutable std::mutex chain_mu;
+  mutable hipEvent_t chain_ev[16] = {nullptr};
+  mutable uint32_t chain_n = 0;
+  mutable bool chain_off = false;
   mutable std::mutex llh_mu;
   mutable double* llh_dev = nullptr;
   mutable double* llh_pin = nullptr;
@@ -303,6 +312,7 @@ int kr_index_upload(const kr_index_view* v, int device, uint32_t flags, kr_index
   }
   std::unique_ptr<kr_index> ix(new kr_index());
   ix->device = device;
+  ix->chain_off = getenv("KR_NO_KERNEL_CHAIN") != nullptr;
   int rc = alloc_from_desc(ix.get(), H, L);
   if (rc) {
     kr_index_free(ix.release());
@@ -365,6 +375,8 @@ void kr_index_free(kr_index* ix)
   for (void* p : ix->allocs) (void)hipFree(p);
   if (ix->llh_dev) (void)hipFree(ix->llh_dev);
   if (ix->llh_pin) (void)hipHostFree(ix->llh_pin);
+  for (auto& e : ix->chain_ev)
+    if (e) (void)hipEventDestroy(e);
   delete ix;
 }
 
@@ -400,6 +412,7 @@ int kr_index_import(const void* desc, uint64_t desc_bytes, int device, kr_index*
   HIP_TRY(hipSetDevice(device));
   std::unique_ptr<kr_index> ix(new kr_index());
   ix->device = device;
+  ix->chain_off = getenv("KR_NO_KERNEL_CHAIN") != nullptr;
   int rc = alloc_from_desc(ix.get(), H, L);
   if (rc) {
     kr_index_free(ix.release());
@@ -662,6 +675,10 @@ int launch_lane(kr_stream* s, Lane& L, uint32_t flags)
   HIP_TRY(hipMemsetAsync(o.cursors, 0, 3 * kCursors * kCursorStride * 4, st));
   HIP_TRY(hipMemsetAsync(o.rec_key, 0, (uint64_t)o.rec_cap * 4, st));
   HIP_TRY(hipMemsetAsync(o.rec_sel, 0, (uint64_t)o.rec_cap, st));
+  // the kernel chain of the index (see kr_index): wait for the previous batch's kernels, record behind ours
+  const kr_index* ixp = s->ix;
+  std::unique_lock<std::mutex> chain(ixp->chain_mu);
+  if (!ixp->chain_off && ixp->chain_n) HIP_TRY(hipStreamWaitEvent(st, ixp->chain_ev[(ixp->chain_n - 1) % 16], 0));
   HIP_TRY(hipEventRecord(L.ev[1], st));
   const DevIndex& dix = s->ix->dix;
   {
@@ -744,6 +761,13 @@ int launch_lane(kr_stream* s, Lane& L, uint32_t flags)
   if (L.rec_base) // the result view indexes the stream's arrays, the lane's kernels its slice
     hipLaunchKernelGGL(kr_rebase_kernel, dim3(std::min<uint32_t>((nreads + 255) / 256, 1024u)), dim3(256), 0, st, o.rd_off, o.rd_cnt, nreads, L.rec_base);
   HIP_TRY(hipEventRecord(L.ev[4], st));
+  if (!ixp->chain_off) {
+    hipEvent_t& ce = ixp->chain_ev[ixp->chain_n % 16];
+    if (!ce) HIP_TRY(hipEventCreateWithFlags(&ce, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ce, st));
+    ++ixp->chain_n;
+  }
+  chain.unlock();
   HIP_TRY(hipMemcpyAsync(L.h_counters, o.counters, 128, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipGetLastError());
   return KR_OK;
