@@ -339,6 +339,14 @@ typedef struct kr_placement {
 KR_API int kr_place_batch(const kr_host_index*, const kr_index*, const kr_place_tree*, const kr_result_view* rv,
                           const uint64_t* offsets, const char* const* names, const kr_params* p, int tabular,
                           int* has_previous, char** text, uint64_t* len, kr_placement** placements, uint64_t* nplacements);
+/* The same for the batch last submitted on `s` (KR_TAP_ACCS; no collect needed): the whole back end of
+ * report_placement up to the candidate list -- ancestor accumulation (Minfo::add, src/query.hpp:139-152;
+ * src/query.cpp:248-265), candidate listing (:268-272), Brent on the internal candidates (:273-275) and the
+ * chi-square of every candidate (:276) -- runs on the device, on the records where they lie; the host receives
+ * the candidates and does the last phase (filter, LWR, Jukes-Cantor, text).  Output identical to kr_place_batch. */
+KR_API int kr_place_stream(const kr_host_index*, const kr_index*, const kr_place_tree*, kr_stream* s, uint32_t nreads,
+                           const uint64_t* offsets, const char* const* names, const kr_params* p, int tabular,
+                           int* has_previous, char** text, uint64_t* len, kr_placement** placements, uint64_t* nplacements);
 /* `tabular`: 0 jplace, 1 --tabular, 2 --summarize (no per-read text; feed the placements to
  * kr_place_summary_add).  place --summarize (src/krepp.cpp:466-471,493-497): `wcount` has
  * kr_place_tree_nnodes + 1 doubles, zeroed by the caller before the first batch and indexed by edge + 1. */

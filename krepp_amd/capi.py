@@ -89,7 +89,7 @@ EXPORTS = [
     "kr_batch_collect", "kr_batch_collect_device", "kr_batch_hits", "kr_batch_readtaps",
     "kr_debug_front_end", "kr_debug_brent", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
     "kr_place_tree_create", "kr_place_tree_create_lineage", "kr_place_tree_nnodes", "kr_place_summary_add",
-    "kr_place_summary_text", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_frame",
+    "kr_place_summary_text", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_stream", "kr_place_frame",
     "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_format_dist", "kr_free", "kr_host_alloc", "kr_host_free",
     "kr_build_index", "kr_minimizers_cpu", "kr_minimizers_device", "kr_minimizers_free", "kr_last_error", "kr_version",
 ]
@@ -162,6 +162,8 @@ def load():
     lib.kr_place_tree_kinds.restype = u8p
     lib.kr_place_batch.argtypes = [vp, vp, vp, C.POINTER(KrResultView), vp, C.POINTER(C.c_char_p), C.POINTER(KrParams), C.c_int,
                                    C.POINTER(C.c_int), C.POINTER(vp), u64p, C.POINTER(vp), u64p]
+    lib.kr_place_stream.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, C.POINTER(C.c_char_p), C.POINTER(KrParams), C.c_int,
+                                    C.POINTER(C.c_int), C.POINTER(vp), u64p, C.POINTER(vp), u64p]
     lib.kr_place_frame.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_uint64, C.POINTER(vp), u64p]
     lib.kr_fastx_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.kr_fastx_next.argtypes = [vp, C.c_uint64, C.POINTER(KrFastxBatch)]
@@ -594,16 +596,23 @@ class Placer:
         self.lib.kr_free(txt)
         return s
 
-    def place(self, bases, offsets, names):
+    def place(self, bases, offsets, names, host=False, c_names=None):
+        """One batch.  host=False: kr_place_stream (tree aggregation and likelihoods on the device);
+        host=True: kr_batch_collect + kr_place_batch (aggregation on the host).  Same output."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self.st.submit(bases, offsets, KR_TAP_ACCS)
-        rv = KrResultView()
-        check(self.lib.kr_batch_collect(self.st.h, C.byref(rv)))
-        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        arr = c_names if c_names is not None else (C.c_char_p * len(names))(*[n.encode() for n in names])
         txt, ln, pls, npl = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64()
-        check(self.lib.kr_place_batch(self.hx.h, self.dx.h, self.pt, C.byref(rv), offsets.ctypes.data, arr, C.byref(self.popts),
-                                      int(self.tabular), C.byref(self.prev), C.byref(txt), C.byref(ln), C.byref(pls), C.byref(npl)))
+        if host:
+            rv = KrResultView()
+            check(self.lib.kr_batch_collect(self.st.h, C.byref(rv)))
+            check(self.lib.kr_place_batch(self.hx.h, self.dx.h, self.pt, C.byref(rv), offsets.ctypes.data, arr, C.byref(self.popts),
+                                          int(self.tabular), C.byref(self.prev), C.byref(txt), C.byref(ln), C.byref(pls), C.byref(npl)))
+        else:
+            check(self.lib.kr_place_stream(self.hx.h, self.dx.h, self.pt, self.st.h, len(offsets) - 1, offsets.ctypes.data, arr,
+                                           C.byref(self.popts), int(self.tabular), C.byref(self.prev), C.byref(txt), C.byref(ln),
+                                           C.byref(pls), C.byref(npl)))
         text = C.string_at(txt, ln.value).decode()
         pl = (np.frombuffer(C.string_at(pls, npl.value * PLACEMENT_DT.itemsize), dtype=PLACEMENT_DT).copy()
               if npl.value else np.zeros(0, PLACEMENT_DT))

@@ -114,6 +114,34 @@ void extract_contig_cpu(const uint8_t* seq, uint64_t len, const BuildCfg& c, con
 // minimizer is emitted there; `x` is its k-mer code, `z` its hash.
 bool contig_end_special(const uint8_t* seq, uint64_t len, const BuildCfg& c, uint64_t& x, uint64_t& z);
 
+// ---- `place` back end on the device (kr_device.hip), driven by kr_place.cpp ----
+// The placement tree as flat arrays over its nodes q = 1..pn (q = post-order number, so the subtree of q is the
+// range [lo[q], q]); idx_to_pt maps an index colour id (leaf se of the index tree) to its placement-tree node.
+struct PlaceTreeArrays {
+  uint32_t pn = 0, nidx = 0;
+  const uint32_t* parent = nullptr; // [pn + 1]
+  const uint32_t* eff = nullptr;    // [pn + 1] Node::get_eff_nchildren
+  const uint8_t* elig = nullptr;    // [pn + 1] nchildren == eff_nchildren && nchildren != 1 (src/query.cpp:270)
+  const uint32_t* lo = nullptr;     // [pn + 1] smallest node number in the subtree of q
+  const uint32_t* idx_to_pt = nullptr; // [nidx + 1]
+};
+struct PlaceDeviceResult { // page-locked host arrays owned by the stream, valid until its next place call / batch
+  uint32_t nreads = 0;
+  const uint32_t* rd_c0 = nullptr;   // [nreads] first candidate slot of the read
+  const uint32_t* rd_info = nullptr; // [nreads] bit 31: reported, bit 30: single placement, low 30 bits: candidates
+  const uint32_t* c_se = nullptr;    // per candidate slot: placement-tree node, d_llh, v_llh, chi-square
+  const double *c_d = nullptr, *c_v = nullptr, *c_chisq = nullptr;
+  bool overflow = false;             // a read exceeded the kernel's per-read limits: take the host path for the batch
+};
+} // namespace kr
+struct kr_stream;
+namespace kr {
+// For the batch last submitted on `s` (KR_TAP_ACCS) and waited for: ancestor accumulation (Minfo::add,
+// src/query.hpp:139-152), candidate listing (src/query.cpp:268-281), Brent on the internal candidates and the
+// chi-square of every candidate against the read's closest leaf, all on the device.
+int place_on_device(kr_stream* s, const void* tree_tag, const PlaceTreeArrays& T, const uint32_t* read_len, uint32_t tau,
+                    bool no_filter, PlaceDeviceResult* out);
+
 } // namespace kr
 
 #endif

@@ -39,6 +39,7 @@
 //   kr_dev_scan.inc        kernel 1: probe list, bucket scan, hit items
 //   kr_dev_accumulate.inc  kernel 2: event epilogue, plane tables, records
 //   kr_dev_likelihood.inc  likelihood, Brent, de-duplication, selection kernels
+//   kr_dev_place.inc       back end of `place`: ancestor accumulation, candidates, their likelihoods (kr_place_kernel)
 //   kr_dev_debug.inc       debug / tap kernels and the re-layout kernels of kr_index_upload
 // and, in this file, the host side: kr_index_upload / export / import, kr_stream_*, kr_batch_*, kr_llh_batch.
 #include <hip/hip_runtime.h>
@@ -65,6 +66,7 @@ namespace {
 #include "kr_dev_scan.inc"
 #include "kr_dev_accumulate.inc"
 #include "kr_dev_likelihood.inc"
+#include "kr_dev_place.inc"
 #include "kr_dev_debug.inc"
 
 // ---------------------------------------------------------------------------
@@ -614,6 +616,19 @@ struct kr_stream {
   double *h_rec_d = nullptr, *h_rec_v = nullptr, *h_rec_chisq = nullptr;
   kr_hit* h_hits = nullptr;
   std::vector<void*> hallocs;
+  // `place` back end on the device (kr::place_on_device): the placement tree as device arrays (for one tree at a
+  // time), per-read / per-candidate outputs and their page-locked mirrors; grown on demand
+  struct PlaceWs {
+    const void* tree_tag = nullptr;
+    uint32_t pn = 0, nidx = 0;
+    uint32_t *d_parent = nullptr, *d_eff = nullptr, *d_lo = nullptr, *d_idx_to_pt = nullptr;
+    uint8_t* d_elig = nullptr;
+    uint32_t *d_len = nullptr, *d_c0 = nullptr, *d_info = nullptr, *d_cse = nullptr, *d_cnt = nullptr;
+    double *d_cd = nullptr, *d_cv = nullptr, *d_cchi = nullptr;
+    uint32_t *h_len = nullptr, *h_c0 = nullptr, *h_info = nullptr, *h_cse = nullptr, *h_cnt = nullptr;
+    double *h_cd = nullptr, *h_cv = nullptr, *h_cchi = nullptr;
+    uint64_t reads_cap = 0, cand_cap = 0, h_cand_cap = 0;
+  } pw;
   // state
   uint64_t h_rec_cap = 0; // pinned record buffers grow on demand in kr_batch_collect
   bool h_rec_full = false; // ... and hold v / chisq / hist only once a batch asked for them
@@ -927,6 +942,14 @@ void kr_stream_destroy(kr_stream* s)
   (void)hipSetDevice(s->device);
   for (auto& L : s->lanes)
     if (L.stream) (void)hipStreamSynchronize(L.stream);
+  {
+    kr_stream::PlaceWs& w = s->pw;
+    for (void* p : {(void*)w.d_parent, (void*)w.d_eff, (void*)w.d_lo, (void*)w.d_idx_to_pt, (void*)w.d_elig, (void*)w.d_len, (void*)w.d_c0,
+                    (void*)w.d_info, (void*)w.d_cse, (void*)w.d_cnt, (void*)w.d_cd, (void*)w.d_cv, (void*)w.d_cchi})
+      if (p) (void)hipFree(p);
+    for (void* p : {(void*)w.h_len, (void*)w.h_c0, (void*)w.h_info, (void*)w.h_cse, (void*)w.h_cnt, (void*)w.h_cd, (void*)w.h_cv, (void*)w.h_cchi})
+      if (p) (void)hipHostFree(p);
+  }
   for (void* p : s->dallocs) (void)hipFree(p);
   for (void* p : s->hallocs) (void)hipHostFree(p);
   for (auto& L : s->lanes) {
@@ -1258,6 +1281,93 @@ int kr_batch_timing(kr_stream* s, kr_timing* t)
   t->stack_spills = s->h_counters[26];
   return KR_OK;
 }
+
+} // extern "C"
+
+// `place` back end for the batch last submitted on the stream (see kr_common.h)
+int kr::place_on_device(kr_stream* s, const void* tree_tag, const kr::PlaceTreeArrays& T, const uint32_t* read_len, uint32_t tau,
+                        bool no_filter, kr::PlaceDeviceResult* out)
+{
+  if (!s || !out || !read_len || !T.parent || !T.eff || !T.elig || !T.lo || !T.idx_to_pt) return kr::fail(KR_ERR_ARG, "place_on_device: null argument");
+  int rc = kr_batch_wait(s);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(s->device));
+  kr_stream::PlaceWs& w = s->pw;
+  hipStream_t st = s->lanes[0].stream;
+  auto dev_renew = [&](auto*& p, uint64_t n) -> int {
+    if (p) (void)hipFree(p), p = nullptr;
+    HIP_TRY(hipMalloc((void**)&p, std::max<uint64_t>(16, n * sizeof(*p))));
+    return KR_OK;
+  };
+  auto pin_renew = [&](auto*& p, uint64_t n) -> int {
+    if (p) (void)hipHostFree(p), p = nullptr;
+    HIP_TRY(hipHostMalloc((void**)&p, std::max<uint64_t>(16, n * sizeof(*p)), hipHostMallocDefault));
+    return KR_OK;
+  };
+  if (w.tree_tag != tree_tag || w.pn != T.pn || w.nidx != T.nidx) { // the tree as device arrays (once per tree)
+    w.tree_tag = nullptr;
+    const uint64_t n1 = (uint64_t)T.pn + 1, n2 = (uint64_t)T.nidx + 1;
+    if ((rc = dev_renew(w.d_parent, n1)) || (rc = dev_renew(w.d_eff, n1)) || (rc = dev_renew(w.d_lo, n1)) || (rc = dev_renew(w.d_elig, n1)) ||
+        (rc = dev_renew(w.d_idx_to_pt, n2)))
+      return rc;
+    HIP_TRY(hipMemcpy(w.d_parent, T.parent, n1 * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(w.d_eff, T.eff, n1 * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(w.d_lo, T.lo, n1 * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(w.d_elig, T.elig, n1, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(w.d_idx_to_pt, T.idx_to_pt, n2 * 4, hipMemcpyHostToDevice));
+    w.tree_tag = tree_tag, w.pn = T.pn, w.nidx = T.nidx;
+  }
+  const uint32_t n = s->nreads;
+  if (n > w.reads_cap) {
+    const uint64_t cap = (uint64_t)n + n / 4;
+    if ((rc = dev_renew(w.d_len, cap)) || (rc = dev_renew(w.d_c0, cap)) || (rc = dev_renew(w.d_info, cap)) || (rc = pin_renew(w.h_len, cap)) ||
+        (rc = pin_renew(w.h_c0, cap)) || (rc = pin_renew(w.h_info, cap)))
+      return rc;
+    if (!w.d_cnt && ((rc = dev_renew(w.d_cnt, 4)) || (rc = pin_renew(w.h_cnt, 4)))) return rc;
+    w.reads_cap = cap;
+  }
+  { // candidate slots: every leaf and every distinct ancestor of a read may be one; a batch that needs more reports it
+    const uint64_t want = std::max<uint64_t>(1u << 20, (uint64_t)n * 24);
+    if (want > w.cand_cap) {
+      if ((rc = dev_renew(w.d_cse, want)) || (rc = dev_renew(w.d_cd, want)) || (rc = dev_renew(w.d_cv, want)) || (rc = dev_renew(w.d_cchi, want))) return rc;
+      w.cand_cap = want;
+    }
+  }
+  memcpy(w.h_len, read_len, (uint64_t)n * 4);
+  HIP_TRY(hipMemcpyAsync(w.d_len, w.h_len, (uint64_t)n * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(w.d_cnt, 0, 16, st));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+  PlaceTree PT{w.d_parent, w.d_eff, w.d_elig, w.d_lo, w.d_idx_to_pt, T.pn, T.nidx};
+  PlaceOut PO{w.d_c0, w.d_info, w.d_cse, w.d_cd, w.d_cv, w.d_cchi, w.d_cnt, (uint32_t)std::min<uint64_t>(w.cand_cap, 0xFFFFFFFFu)};
+  const uint32_t grid = std::min<uint32_t>(n, (uint32_t)prop.multiProcessorCount * 12u);
+  hipLaunchKernelGGL(kr_place_kernel, dim3(grid), dim3(kWave), 0, st, s->llh, s->ix->dix, s->out, n, w.d_len, PT, PO, tau, no_filter ? 1u : 0u);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(w.h_cnt, w.d_cnt, 16, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(w.h_c0, w.d_c0, (uint64_t)n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(w.h_info, w.d_info, (uint64_t)n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  out->nreads = n;
+  out->overflow = w.h_cnt[1] != 0;
+  if (out->overflow) return KR_OK;
+  const uint64_t used = std::min<uint64_t>(w.h_cnt[0], w.cand_cap);
+  if (used > w.h_cand_cap) {
+    const uint64_t cap = used + used / 4 + 1024;
+    if ((rc = pin_renew(w.h_cse, cap)) || (rc = pin_renew(w.h_cd, cap)) || (rc = pin_renew(w.h_cv, cap)) || (rc = pin_renew(w.h_cchi, cap))) return rc;
+    w.h_cand_cap = cap;
+  }
+  if (used) {
+    HIP_TRY(hipMemcpyAsync(w.h_cse, w.d_cse, used * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(w.h_cd, w.d_cd, used * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(w.h_cv, w.d_cv, used * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(w.h_cchi, w.d_cchi, used * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  out->rd_c0 = w.h_c0, out->rd_info = w.h_info, out->c_se = w.h_cse, out->c_d = w.h_cd, out->c_v = w.h_cv, out->c_chisq = w.h_cchi;
+  return KR_OK;
+}
+
+extern "C" {
 
 void* kr_host_alloc(uint64_t bytes)
 {

@@ -32,6 +32,10 @@ struct kr_place_tree {
   std::vector<uint32_t> idx_to_pt; // index colour id of a leaf -> se in the placement tree (0 = absent)
   std::vector<uint8_t> kinds;     // node_kind array for kr_index_upload
   uint32_t root = 0;
+  // flat arrays for the device back end (kr::place_on_device): parent, subtree start, candidate eligibility
+  std::vector<uint32_t> parent_arr, lo;
+  std::vector<uint8_t> elig;
+  bool postorder = false; // every subtree is the node range [lo[q], q]: what the device kernel's ancestor listing needs
 };
 
 namespace {
@@ -332,6 +336,190 @@ void finish_tree(kr_place_tree& ptr, const kr_index_view& v, bool mapped, bool d
     for (uint32_t se = 1; se <= pn; ++se)
       if (covered[se] && pt->t.nodes[se].parent) pt->eff[pt->t.nodes[se].parent]++;
   }
+  // flat arrays for the device back end
+  pt->parent_arr.assign(pn + 1, 0), pt->lo.assign(pn + 1, 0), pt->elig.assign(pn + 1, 0);
+  std::vector<uint32_t> size(pn + 1, 1);
+  pt->postorder = true;
+  for (uint32_t se = 1; se <= pn; ++se) {
+    const uint32_t par = pt->t.nodes[se].parent;
+    pt->parent_arr[se] = par;
+    pt->lo[se] = se;
+    const uint32_t nch = (uint32_t)pt->kids[se].size();
+    pt->elig[se] = (nch == pt->eff[se] && nch != 1) ? 1 : 0; // src/query.cpp:270
+    if (par && par <= se) pt->postorder = false;
+  }
+  if (pt->postorder) {
+    for (uint32_t se = 1; se <= pn; ++se) { // children precede parents: sizes and range starts flow upwards
+      const uint32_t par = pt->parent_arr[se];
+      if (par) size[par] += size[se], pt->lo[par] = std::min(pt->lo[par], pt->lo[se]);
+    }
+    for (uint32_t se = 1; se <= pn; ++se)
+      if (se - pt->lo[se] + 1 != size[se]) pt->postorder = false; // the subtree is not a contiguous range of numbers
+  }
+}
+
+} // namespace
+
+
+namespace {
+
+struct ReadPlan {
+  bool reported = false, single = false;
+  size_t c0 = 0, c1 = 0; // candidate range
+  int closest = -1;      // (host path) index into its closest-leaf list
+  uint32_t closest_pt = 0;
+};
+struct CandLite { // what the last phase needs of a candidate
+  uint32_t se;
+  double d, v, chisq, lwr;
+  double jc() const { return -0.75 * log(1 - 4.0 / 3.0 * d); }
+};
+
+// Last phase of report_placement (src/query.cpp:283-331) for a whole batch: chi-square filter, LWR, selection, text.
+// `cand(i)` gives candidate i; a read's candidates [c0, c1) are in ascending node number.
+int emit_placements(const kr_place_tree* pt, uint32_t nreads, const std::vector<ReadPlan>& plan, std::vector<CandLite>& cands,
+                    const char* const* names, const kr_params* p, int tabular, int* has_previous, char** text, uint64_t* len,
+                    kr_placement** placements, uint64_t* nplacements, const std::function<void(const char*)>& lap)
+{
+  const int nt = std::max(1, std::min(std::min(kr::parallel_width(), 32), (int)(nreads / 4096)));
+  auto en = [&](uint32_t q) { return q - 1; };
+  auto mid = [&](uint32_t q) { return std::isnan(pt->t.nodes[q].blen) ? 0.0 : pt->t.nodes[q].blen / 2.0; };
+  auto num = [](std::string& o, double v) {
+    char b[64];
+    if (std::isnan(v)) {
+      o += std::signbit(v) ? "-nan" : "nan";
+      return;
+    }
+    o.append(b, kr::fmt_fixed5(v, b));
+  };
+  auto jfields = [&](std::string& o, uint32_t q, const CandLite& a) {
+    o += '[';
+    o += std::to_string(en(q));
+    o += ", ", num(o, a.jc() - mid(q));
+    o += ", ", num(o, mid(q));
+    o += ", ", num(o, -a.v);
+    o += ", ", num(o, a.lwr);
+    o += ", ", num(o, a.d);
+    o += ']';
+  };
+  auto tfields = [&](std::string& o, uint32_t q, const CandLite& a) {
+    const std::string& nm = pt->t.nodes[q].label;
+    o += nm.empty() ? std::string("NA") : nm;
+    o += '\t';
+    o += std::to_string(en(q));
+    o += '\t', num(o, a.lwr);
+    o += '\t', num(o, a.d);
+  };
+  const bool jp = tabular == 0, tb = tabular == 1; // 2: --summarize, no text (the caller sums the placements)
+  std::vector<std::string> part((size_t)nt);
+  std::vector<std::vector<kr_placement>> ppls((size_t)nt);
+  kr::parallel_for(nt, [&](int t) {
+    const uint32_t ra = (uint32_t)((uint64_t)nreads * t / nt), rb = (uint32_t)((uint64_t)nreads * (t + 1) / nt);
+    std::string& out = part[(size_t)t];
+    std::vector<kr_placement>& pls = ppls[(size_t)t];
+    bool prev = false; // within the piece; pieces are joined with the separator below
+    auto record = [&](uint32_t r, uint32_t q, const CandLite& a) {
+      kr_placement x;
+      x.read = r, x.edge = en(q), x.lwr = a.lwr, x.d_llh = a.d, x.v_llh = a.v, x.pendant = a.jc() - mid(q), x.distal = mid(q);
+      pls.push_back(x);
+    };
+    std::vector<size_t> nd_v;
+    for (uint32_t r = ra; r < rb; ++r) {
+      const ReadPlan& pl = plan[r];
+      if (!pl.reported) continue;
+      const char* id = names ? names[r] : "";
+      if (jp) {
+        if (prev) out += ",\n";
+        out += "\t\t\t{\"n\" : [\"";
+        out += id;
+        out += "\"], \"p\" : [";
+        prev = true;
+      }
+      if (pl.single) {
+        CandLite& c = cands[pl.c0];
+        record(r, c.se, c);
+        if (tb)
+          out += id, out += '\t', tfields(out, c.se, c), out += '\n';
+        else if (jp)
+          jfields(out, c.se, c), out += "]}";
+        continue;
+      }
+      nd_v.clear();
+      for (size_t i = pl.c0; i < pl.c1; ++i)
+        if (cands[i].chisq < p->chisq && pt->t.nodes[cands[i].se].parent) nd_v.push_back(i);
+      double total = 0;
+      for (size_t i : nd_v) {
+        cands[i].lwr = exp(-cands[i].chisq / 2);
+        total = total + cands[i].lwr;
+      }
+      if (p->multi) {
+        for (size_t j2 = 0; j2 < nd_v.size(); ++j2) {
+          CandLite& c = cands[nd_v[j2]];
+          c.lwr = c.lwr / total;
+          record(r, c.se, c);
+          if (j2 > 0 && jp) out += ",";
+          if (tb)
+            out += id, out += '\t', tfields(out, c.se, c), out += '\n';
+          else if (jp)
+            out += "\n\t\t\t\t", jfields(out, c.se, c);
+        }
+        if (jp) out += "]\n\t\t\t}";
+      } else {
+        if (nd_v.size() > 1)
+          std::stable_sort(nd_v.begin(), nd_v.end(), [&](size_t l, size_t rr) {
+            uint32_t cl_ = pt->card[cands[l].se], cr = pt->card[cands[rr].se];
+            return cl_ == cr ? cands[l].d > cands[rr].d : cl_ < cr;
+          });
+        if (nd_v.empty()) {
+          if (jp) out += "]}";
+          continue;
+        }
+        CandLite& c = cands[nd_v.back()];
+        c.lwr = c.lwr / total;
+        record(r, c.se, c);
+        if (tb)
+          out += id, out += '\t', tfields(out, c.se, c), out += '\n';
+        else if (jp)
+          jfields(out, c.se, c), out += "]}";
+      }
+    }
+  });
+  lap("D: filter + text");
+  // pieces joined in order, straight into the buffer the caller receives
+  bool prev = *has_previous != 0;
+  std::vector<size_t> at((size_t)nt + 1, 0), sep((size_t)nt, 0), pat((size_t)nt + 1, 0);
+  for (int t = 0; t < nt; ++t) {
+    if (!part[(size_t)t].empty()) {
+      sep[(size_t)t] = (jp && prev) ? 2 : 0;
+      if (jp) prev = true;
+    }
+    at[(size_t)t + 1] = at[(size_t)t] + sep[(size_t)t] + part[(size_t)t].size();
+    pat[(size_t)t + 1] = pat[(size_t)t] + ppls[(size_t)t].size();
+  }
+  const size_t total_len = at[(size_t)nt], total_pl = pat[(size_t)nt];
+  char* buf = (char*)malloc(total_len + 1);
+  if (!buf) return kr::fail(KR_ERR_NOMEM, "kr_place_batch: out of memory");
+  kr_placement* pbuf = nullptr;
+  if (placements && nplacements) {
+    pbuf = (kr_placement*)malloc(std::max<size_t>(1, total_pl) * sizeof(kr_placement));
+    if (!pbuf) {
+      free(buf);
+      return kr::fail(KR_ERR_NOMEM, "kr_place_batch: out of memory");
+    }
+  }
+  kr::parallel_for(nt, [&](int t) {
+    char* o = buf + at[(size_t)t];
+    if (sep[(size_t)t]) o[0] = ',', o[1] = '\n', o += 2;
+    memcpy(o, part[(size_t)t].data(), part[(size_t)t].size());
+    if (pbuf && !ppls[(size_t)t].empty()) memcpy(pbuf + pat[(size_t)t], ppls[(size_t)t].data(), ppls[(size_t)t].size() * sizeof(kr_placement));
+  });
+  buf[total_len] = 0;
+  lap("D: join");
+  *has_previous = prev ? 1 : 0;
+  *text = buf;
+  *len = total_len;
+  if (pbuf) *placements = pbuf, *nplacements = total_pl;
+  return KR_OK;
 }
 
 } // namespace
@@ -381,7 +569,7 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
   const bool timing = getenv("KR_PLACE_TIMING") != nullptr;
   auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_mark = wall();
-  auto lap = [&](const char* what) {
+  std::function<void(const char*)> lap = [&](const char* what) {
     if (!timing) return;
     const double now = wall();
     fprintf(stderr, "[place] %s %.1f ms\n", what, (now - t_mark) * 1e3);
@@ -390,12 +578,6 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
   // ---- phase A (host, one OpenMP thread per range of reads): per read, the leaf set, the closest, ancestor
   //      accumulation, candidates.  Each thread keeps a small open-addressing table node -> accumulator that
   //      is reused from read to read (stamps instead of clearing).
-  struct ReadPlan {
-    bool reported = false, single = false;
-    size_t c0 = 0, c1 = 0; // candidate range in `cands`
-    int closest = -1;      // index into `closest_acc`
-    uint32_t closest_pt = 0;
-  };
   std::vector<ReadPlan> plan(rv->nreads);
   // one thread per ~4096 reads, at most 32: small batches do not pay for waking a large team
   const int nt = std::max(1, std::min(std::min(kr::parallel_width(), 32), (int)(rv->nreads / 4096)));
@@ -577,135 +759,85 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
     });
   }
   lap("C: chi-square evaluations");
-  // ---- phase D (host, the same read ranges in parallel): candidate filter, LWR, text; pieces joined in order
-  auto en = [&](uint32_t q) { return q - 1; };
-  auto mid = [&](uint32_t q) { return std::isnan(pt->t.nodes[q].blen) ? 0.0 : pt->t.nodes[q].blen / 2.0; };
-  auto num = [](std::string& o, double v) {
-    char b[64];
-    if (std::isnan(v)) {
-      o += std::signbit(v) ? "-nan" : "nan";
-      return;
-    }
-    o.append(b, kr::fmt_fixed5(v, b));
+  // ---- phase D: chi-square filter, LWR, selection, text (shared with the device path)
+  std::vector<CandLite> lite(cands.size());
+  ranged(cands.size(), [&](size_t j0, size_t j1) {
+    for (size_t j = j0; j < j1; ++j) lite[j] = CandLite{cands[j]->se, cands[j]->a.d, cands[j]->a.v, cands[j]->a.chisq, cands[j]->a.lwr};
+  });
+  return emit_placements(pt, rv->nreads, plan, lite, names, p, tabular, has_previous, text, len, placements, nplacements, lap);
+}
+
+// As kr_place_batch, for the batch last submitted on `s` with KR_TAP_ACCS, which need not be collected: the tree
+// aggregation, the Brent minimisations of the internal candidates and the chi-squares run on the device
+// (kr_place_kernel) on the records where they lie; what comes back is the candidates (node, d, v, chi-square), and the
+// host does the last phase only (filter, exp / LWR, Jukes-Cantor, text).  Bit-identical to kr_place_batch.  Reads
+// beyond the kernel's per-read limits (256 leaves / 1024 ancestors), or a placement tree whose numbering is not
+// post-order, send the whole batch through kr_place_batch.
+int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place_tree* pt, kr_stream* s, uint32_t nreads,
+                    const uint64_t* offsets, const char* const* names, const kr_params* p, int tabular, int* has_previous, char** text,
+                    uint64_t* len, kr_placement** placements, uint64_t* nplacements)
+{
+  kr::clear_error();
+  if (!hx || !dix || !pt || !s || !offsets || !p || !has_previous || !text || !len || !nreads)
+    return kr::fail(KR_ERR_ARG, "kr_place_stream: null argument");
+  auto host_path = [&]() -> int {
+    kr_result_view rv;
+    int rc = kr_batch_collect(s, &rv);
+    if (rc) return rc;
+    if (rv.nreads != nreads) return kr::fail(KR_ERR_ARG, "kr_place_stream: nreads does not match the submitted batch");
+    return kr_place_batch(hx, dix, pt, &rv, offsets, names, p, tabular, has_previous, text, len, placements, nplacements);
   };
-  auto jfields = [&](std::string& o, uint32_t q, const Acc& a) {
-    o += '[';
-    o += std::to_string(en(q));
-    o += ", ", num(o, a.jc() - mid(q));
-    o += ", ", num(o, mid(q));
-    o += ", ", num(o, -a.v);
-    o += ", ", num(o, a.lwr);
-    o += ", ", num(o, a.d);
-    o += ']';
+  if (!pt->postorder || getenv("KR_PLACE_HOST")) return host_path();
+  const bool timing = getenv("KR_PLACE_TIMING") != nullptr;
+  auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = wall();
+  std::function<void(const char*)> lap = [&](const char* what) {
+    if (!timing) return;
+    const double now = wall();
+    fprintf(stderr, "[place/device] %s %.1f ms\n", what, (now - t_mark) * 1e3);
+    t_mark = now;
   };
-  auto tfields = [&](std::string& o, uint32_t q, const Acc& a) {
-    const std::string& nm = pt->t.nodes[q].label;
-    o += nm.empty() ? std::string("NA") : nm;
-    o += '\t';
-    o += std::to_string(en(q));
-    o += '\t', num(o, a.lwr);
-    o += '\t', num(o, a.d);
-  };
-  const bool jp = tabular == 0, tb = tabular == 1; // 2: --summarize, no text (the caller sums the placements)
-  std::vector<std::string> part((size_t)nt);
-  std::vector<std::vector<kr_placement>> ppls((size_t)nt);
+  const int nt = std::max(1, std::min(std::min(kr::parallel_width(), 32), (int)(nreads / 4096)));
+  std::vector<uint32_t> read_len(nreads);
   kr::parallel_for(nt, [&](int t) {
-    const uint32_t ra = (uint32_t)((uint64_t)rv->nreads * t / nt), rb = (uint32_t)((uint64_t)rv->nreads * (t + 1) / nt);
-    std::string& out = part[(size_t)t];
-    std::vector<kr_placement>& pls = ppls[(size_t)t];
-    bool prev = false; // within the piece; pieces are joined with the separator below
-    auto record = [&](uint32_t r, uint32_t q, const Acc& a) {
-      kr_placement x;
-      x.read = r, x.edge = en(q), x.lwr = a.lwr, x.d_llh = a.d, x.v_llh = a.v, x.pendant = a.jc() - mid(q), x.distal = mid(q);
-      pls.push_back(x);
-    };
-    std::vector<size_t> nd_v;
-    for (uint32_t r = ra; r < rb; ++r) {
+    for (size_t r = (size_t)nreads * t / nt; r < (size_t)nreads * (t + 1) / nt; ++r) read_len[r] = (uint32_t)(offsets[r + 1] - offsets[r]);
+  });
+  kr::PlaceTreeArrays T;
+  T.pn = pt->t.nnodes(), T.nidx = (uint32_t)pt->idx_to_pt.size() - 1;
+  T.parent = pt->parent_arr.data(), T.eff = pt->eff.data(), T.elig = pt->elig.data(), T.lo = pt->lo.data(), T.idx_to_pt = pt->idx_to_pt.data();
+  kr::PlaceDeviceResult res;
+  int rc = kr::place_on_device(s, pt, T, read_len.data(), p->tau, p->no_filter != 0, &res);
+  if (rc) return rc;
+  if (res.nreads != nreads) return kr::fail(KR_ERR_ARG, "kr_place_stream: nreads does not match the submitted batch");
+  lap("A-C: aggregation, Brent, chi-square on the device + copy back");
+  if (res.overflow) return host_path();
+  // candidates in read order, each read's in ascending node number (the order the host path forms them in)
+  std::vector<ReadPlan> plan(nreads);
+  std::vector<size_t> base((size_t)nt + 1, 0);
+  kr::parallel_for(nt, [&](int t) {
+    size_t c = 0;
+    for (size_t r = (size_t)nreads * t / nt; r < (size_t)nreads * (t + 1) / nt; ++r)
+      if (res.rd_info[r] >> 31) c += res.rd_info[r] & 0x3FFFFFFFu;
+    base[(size_t)t + 1] = c;
+  });
+  for (int t = 0; t < nt; ++t) base[(size_t)t + 1] += base[(size_t)t];
+  std::vector<CandLite> cands(base[(size_t)nt]);
+  kr::parallel_for(nt, [&](int t) {
+    size_t at = base[(size_t)t];
+    for (size_t r = (size_t)nreads * t / nt; r < (size_t)nreads * (t + 1) / nt; ++r) {
+      const uint32_t info = res.rd_info[r];
+      if (!(info >> 31)) continue;
       ReadPlan& pl = plan[r];
-      if (!pl.reported) continue;
-      const char* id = names ? names[r] : "";
-      if (jp) {
-        if (prev) out += ",\n";
-        out += "\t\t\t{\"n\" : [\"";
-        out += id;
-        out += "\"], \"p\" : [";
-        prev = true;
-      }
-      if (pl.single) {
-        Cand& c = *cands[pl.c0];
-        record(r, c.se, c.a);
-        if (tb)
-          out += id, out += '\t', tfields(out, c.se, c.a), out += '\n';
-        else if (jp)
-          jfields(out, c.se, c.a), out += "]}";
-        continue;
-      }
-      nd_v.clear();
-      for (size_t i = pl.c0; i < pl.c1; ++i)
-        if (cands[i]->a.chisq < p->chisq && pt->t.nodes[cands[i]->se].parent) nd_v.push_back(i);
-      double total = 0;
-      for (size_t i : nd_v) {
-        cands[i]->a.lwr = exp(-cands[i]->a.chisq / 2);
-        total = total + cands[i]->a.lwr;
-      }
-      if (p->multi) {
-        for (size_t j2 = 0; j2 < nd_v.size(); ++j2) {
-          Cand& c = *cands[nd_v[j2]];
-          c.a.lwr = c.a.lwr / total;
-          record(r, c.se, c.a);
-          if (j2 > 0 && jp) out += ",";
-          if (tb)
-            out += id, out += '\t', tfields(out, c.se, c.a), out += '\n';
-          else if (jp)
-            out += "\n\t\t\t\t", jfields(out, c.se, c.a);
-        }
-        if (jp) out += "]\n\t\t\t}";
-      } else {
-        if (nd_v.size() > 1)
-          std::stable_sort(nd_v.begin(), nd_v.end(), [&](size_t l, size_t rr) {
-            uint32_t cl_ = pt->card[cands[l]->se], cr = pt->card[cands[rr]->se];
-            return cl_ == cr ? cands[l]->a.d > cands[rr]->a.d : cl_ < cr;
-          });
-        if (nd_v.empty()) {
-          if (jp) out += "]}";
-          continue;
-        }
-        Cand& c = *cands[nd_v.back()];
-        c.a.lwr = c.a.lwr / total;
-        record(r, c.se, c.a);
-        if (tb)
-          out += id, out += '\t', tfields(out, c.se, c.a), out += '\n';
-        else if (jp)
-          jfields(out, c.se, c.a), out += "]}";
-      }
+      const uint32_t n = info & 0x3FFFFFFFu, c0 = res.rd_c0[r];
+      pl.reported = true, pl.single = (info >> 30) & 1u;
+      pl.c0 = at, pl.c1 = at + n;
+      for (uint32_t i = 0; i < n; ++i) cands[at + i] = CandLite{res.c_se[c0 + i], res.c_d[c0 + i], res.c_v[c0 + i], res.c_chisq[c0 + i], 1.0};
+      if (n > 1) std::sort(cands.begin() + (ptrdiff_t)at, cands.begin() + (ptrdiff_t)(at + n), [](const CandLite& a, const CandLite& b) { return a.se < b.se; });
+      at += n;
     }
   });
-  lap("D: filter + text");
-  bool prev = *has_previous != 0;
-  size_t total_len = 0, total_pl = 0;
-  for (int t = 0; t < nt; ++t) total_len += part[(size_t)t].size() + 2, total_pl += ppls[(size_t)t].size();
-  std::string out;
-  out.reserve(total_len);
-  std::vector<kr_placement> pls;
-  pls.reserve(total_pl);
-  for (int t = 0; t < nt; ++t) {
-    if (!part[(size_t)t].empty()) {
-      if (jp && prev) out += ",\n";
-      out += part[(size_t)t];
-      if (jp) prev = true;
-    }
-    pls.insert(pls.end(), ppls[(size_t)t].begin(), ppls[(size_t)t].end());
-  }
-  lap("D: join");
-  *has_previous = prev ? 1 : 0;
-  *text = dup_text(out, len);
-  if (!*text) return kr::fail(KR_ERR_NOMEM, "kr_place_batch: out of memory");
-  if (placements && nplacements) {
-    *nplacements = pls.size();
-    *placements = (kr_placement*)malloc(std::max<size_t>(1, pls.size()) * sizeof(kr_placement));
-    if (!pls.empty()) memcpy(*placements, pls.data(), pls.size() * sizeof(kr_placement));
-  }
-  return KR_OK;
+  lap("candidates in order");
+  return emit_placements(pt, nreads, plan, cands, names, p, tabular, has_previous, text, len, placements, nplacements, lap);
 }
 
 uint32_t kr_place_tree_nnodes(const kr_place_tree* pt) { return pt ? pt->t.nnodes() : 0; }

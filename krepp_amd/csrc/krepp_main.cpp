@@ -300,7 +300,7 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
         auto t_dev = now();
         int rc = kr_batch_submit(st, j->bases.data() + j->offsets[lo], offs.data(), (uint32_t)(hi - lo),
                                  KR_BASES_HOST | (place ? KR_TAP_ACCS : 0u));
-        if (!rc) rc = kr_batch_collect(st, &rv);
+        if (!rc) rc = place ? kr_batch_wait(st) : kr_batch_collect(st, &rv); // place: the records stay on the device
         ns_dev += since(t_dev);
         auto t_fmt = now();
         if (rc == KR_ERR_CAPACITY && hi - lo > 1) {
@@ -325,8 +325,8 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
           int prev = (!tabular && !text.empty()) ? 1 : 0; // pieces of a batch are joined here, batches by the writer (src/krepp.cpp:474-484)
           kr_placement* pp = nullptr;
           uint64_t npp = 0;
-          rc = kr_place_batch(hx, dix[g], ptree, &rv, offs.data(), nm.data() + lo, &p, tabular, &prev, &txt, &len,
-                              tabular == 2 ? &pp : nullptr, tabular == 2 ? &npp : nullptr);
+          rc = kr_place_stream(hx, dix[g], ptree, st, (uint32_t)(hi - lo), offs.data(), nm.data() + lo, &p, tabular, &prev, &txt, &len,
+                               tabular == 2 ? &pp : nullptr, tabular == 2 ? &npp : nullptr);
           for (uint64_t i = 0; i < npp; ++i) {
             pp[i].read = (uint32_t)(j->first_read + lo + pp[i].read);
             pls.push_back(pp[i]);

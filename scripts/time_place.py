@@ -31,9 +31,12 @@ for tab in (0, 1, 2):
                                      C.byref(txt), C.byref(ln), C.byref(pls), C.byref(npl)))
     t3 = time.time()
     print(f"  submit+collect {t1 - t:.3f} s, names {t2 - t1:.3f} s, kr_place_batch {t3 - t2:.3f} s")
-    t = time.time()
-    text, p = pl.place(b, o, names)
-    dt = time.time() - t
+    arr = (C.c_char_p * len(names))(*[x.encode() for x in names])
+    for host in (True, False):
+        t = time.time()
+        text, p = pl.place(b, o, names, host=host, c_names=arr)
+        dt = time.time() - t
+        print(f"  {'host' if host else 'device'} back end, submit to text: {n} reads in {dt:.3f} s = {n / dt / 1e6:.2f} M reads/s")
     tm = pl.st.timing()
     print(f"mode {tab}: {n} reads in {dt:.3f} s = {n / dt / 1e6:.2f} M reads/s; device front end {tm.ms_total:.1f} ms; placements {len(p)}; text MB {len(text) / 1e6:.1f}")
     pl.close()

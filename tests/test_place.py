@@ -255,6 +255,36 @@ def test_cli_place_lineages_and_summarize(po, toy_index_dir, toy_reads, tmp_path
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tree", ["backbone", "user", "lineages"])
+def test_device_back_end_equals_host_back_end(capi, po, toy_index_dir, toy_reads, toy_genomes, synth, tree):
+    """kr_place_stream (ancestor accumulation, candidates, Brent and chi-square in kr_place_kernel) against
+    kr_place_batch (the same on host threads + kr_llh_batch): identical text and placements, bit for bit, on the
+    backbone, on a user tree that lacks some references, and on a lineage tree; all option sets and output modes."""
+    names, bases, offs = toy_reads
+    b2, o2, n2 = synth.sample_reads(toy_genomes, 5000, seed=23)
+    hx = capi.HostIndex(toy_index_dir)
+    kw = {}
+    if tree == "user":
+        nwk = open(os.path.join(GOLDEN, "tree_toy.nwk")).read()
+        kw["nwk_text"] = nwk.replace("(G000735195:0.0276038,G000018865:0.0228997)N2640:0.160977", "(G000735195:0.03,NEWLEAF:0.02)N2640:0.160977")
+        assert kw["nwk_text"] != nwk
+    elif tree == "lineages":
+        kw["lineage_text"] = open(os.path.join(GOLDEN, "lineages_toy.txt")).read()
+    for opts in (dict(), dict(multi=0), dict(tau=1, chisq=3.841), dict(hdist_th=3)):
+        for tabular in (0, 1, 2):
+            for rb, ro, rn in ((bases, offs, names), (b2, o2, n2)):
+                out = []
+                for host in (False, True):
+                    pl = capi.Placer(hx, kw.get("nwk_text"), 0, tabular=tabular, max_reads=len(rn), max_bases=len(rb),
+                                     lineage_text=kw.get("lineage_text"), **opts)
+                    text, p = pl.place(rb, ro, rn, host=host)
+                    out.append((text, p.tobytes(), pl.summary() if tabular == 2 else ""))
+                    pl.close()
+                assert out[0] == out[1], (tree, opts, tabular)
+                assert len(out[0][1]) > 0
+
+
+@pytest.mark.gpu
 def test_large_batch_goes_through_the_thread_pool(capi, po, toy_index_dir, toy_reads):
     """Batches of more than 8,192 reads are cut into ranges handled by several host threads (kr::parallel_for):
     aggregation, candidate lists, text pieces and the jplace separators must come out as for one thread."""
