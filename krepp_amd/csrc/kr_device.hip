@@ -243,6 +243,12 @@ int alloc_from_desc(kr_index* ix, const DescHeader& H, const std::vector<DescLib
 
 constexpr uint32_t kDescMagic = 0x4b524958u; // "KRIX"
 
+// The HIP runtime folds every stream after the third onto its last hardware queue (GPU_MAX_HW_QUEUES, default 4), where
+// the copies of one kr_stream would queue behind the kernels of another as blit kernels instead of running beside them
+// on an SDMA engine.  Raised here, when the library is loaded, unless the host application has set it; it only takes
+// effect if the runtime has not initialised yet.
+__attribute__((constructor)) void kr_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 } // namespace
 
 extern "C" {
@@ -904,7 +910,9 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
   o.bm_words = bm_words;
   for (uint32_t l = 0; l < ML; ++l) {
     Lane& L = s->lanes[l];
-    HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    // HIP streams are a scarce resource (the runtime folds every stream after the third onto one hardware queue unless
+    // GPU_MAX_HW_QUEUES says otherwise): lane 0 has one from the start, the others get theirs when a batch first uses them
+    if (l == 0) HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
     for (auto& e : L.ev) HIP_TRY(hipEventCreate(&e));
     SA(L.d_counters, 32);
     SA(L.d_cursors, 3 * kCursors * kCursorStride);
@@ -918,11 +926,11 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
     SA(L.d_g_list, (uint64_t)s->nwaves * g_list_words);
     // on the lane's own stream and waited for: it does not synchronise with the null stream, and a
     // multi-GB clear (large trees) would otherwise still be running when the first batch arrives
-    HIP_TRY(hipMemsetAsync(L.d_g_planes, 0, (uint64_t)s->nwaves * nslots2 * np * kPlaneWords * 4, L.stream));
-    HIP_TRY(hipMemsetAsync(L.d_g_counts, 0, (uint64_t)s->nwaves * nslots2 * np * 4, L.stream));
+    HIP_TRY(hipMemsetAsync(L.d_g_planes, 0, (uint64_t)s->nwaves * nslots2 * np * kPlaneWords * 4, s->lanes[0].stream));
+    HIP_TRY(hipMemsetAsync(L.d_g_counts, 0, (uint64_t)s->nwaves * nslots2 * np * 4, s->lanes[0].stream));
     HA(L.h_counters, 32);
   }
-  for (uint32_t l = 0; l < ML; ++l) HIP_TRY(hipStreamSynchronize(s->lanes[l].stream));
+  HIP_TRY(hipStreamSynchronize(s->lanes[0].stream));
   HA(s->h_bases, max_bases + 256);
   HA(s->h_offsets, (uint64_t)max_reads + 1);
   HA(s->h_rd_off, max_reads);
@@ -997,6 +1005,7 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
     Lane& L = s->lanes[l];
     const uint32_t r0 = (uint32_t)((uint64_t)nreads * l / P), r1 = (uint32_t)((uint64_t)nreads * (l + 1) / P);
     L.read0 = r0, L.nreads = r1 - r0, L.rec_base = l * lane_rec_cap, L.rec_cap = lane_rec_cap, L.nrecs = 0;
+    if (!L.stream) HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
     hipStream_t st = L.stream;
     HIP_TRY(hipEventRecord(L.ev[0], st));
     if (flags & KR_BASES_DEVICE) {

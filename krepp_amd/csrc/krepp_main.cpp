@@ -557,6 +557,10 @@ static int run_sketch(const Args& a)
 
 int main(int argc, char** argv)
 {
+  // more hardware queues than the runtime's default of 4: with two workers per GPU (each a kr_stream with its own HIP
+  // streams) every stream after the third would share the last queue, and copies queued there turn into blit kernels
+  // behind the other worker's kernels instead of SDMA transfers beside them.  Before the first HIP call.
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   // batches allocate and free tens of MB of rows and text over and over: keep that memory in the heap instead of
   // mapping and unmapping it each time (page faults and mmap locking showed up as 50 ms stalls per batch)
   if (!getenv("KR_CLI_DEFAULT_MALLOC")) {
