@@ -377,7 +377,9 @@ struct CandLite { // what the last phase needs of a candidate
 
 // Last phase of report_placement (src/query.cpp:283-331) for a whole batch: chi-square filter, LWR, selection, text.
 // `cand(i)` gives candidate i; a read's candidates [c0, c1) are in ascending node number.
-int emit_placements(const kr_place_tree* pt, uint32_t nreads, const std::vector<ReadPlan>& plan, std::vector<CandLite>& cands,
+// `src`: reported(r), single(r), fetch(r, buf) -> fills buf with the read's candidates in ascending node number.
+template <typename Source>
+int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
                     const char* const* names, const kr_params* p, int tabular, int* has_previous, char** text, uint64_t* len,
                     kr_placement** placements, uint64_t* nplacements, const std::function<void(const char*)>& lap)
 {
@@ -424,9 +426,13 @@ int emit_placements(const kr_place_tree* pt, uint32_t nreads, const std::vector<
       pls.push_back(x);
     };
     std::vector<size_t> nd_v;
+    std::vector<CandLite> cands; // the read's candidates
+    out.reserve((size_t)(rb - ra) * (jp ? 160 : tb ? 72 : 0) + 64);
+    pls.reserve((size_t)(rb - ra) * 2);
     for (uint32_t r = ra; r < rb; ++r) {
-      const ReadPlan& pl = plan[r];
-      if (!pl.reported) continue;
+      if (!src.reported(r)) continue;
+      struct { bool single; size_t c0, c1; } pl{src.single(r), 0, 0};
+      pl.c1 = src.fetch(r, cands);
       const char* id = names ? names[r] : "";
       if (jp) {
         if (prev) out += ",\n";
@@ -760,11 +766,20 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
   }
   lap("C: chi-square evaluations");
   // ---- phase D: chi-square filter, LWR, selection, text (shared with the device path)
-  std::vector<CandLite> lite(cands.size());
-  ranged(cands.size(), [&](size_t j0, size_t j1) {
-    for (size_t j = j0; j < j1; ++j) lite[j] = CandLite{cands[j]->se, cands[j]->a.d, cands[j]->a.v, cands[j]->a.chisq, cands[j]->a.lwr};
-  });
-  return emit_placements(pt, rv->nreads, plan, lite, names, p, tabular, has_previous, text, len, placements, nplacements, lap);
+  struct HostSource {
+    const std::vector<ReadPlan>& plan;
+    const std::vector<Cand*>& cands;
+    bool reported(uint32_t r) const { return plan[r].reported; }
+    bool single(uint32_t r) const { return plan[r].single; }
+    size_t fetch(uint32_t r, std::vector<CandLite>& buf) const
+    {
+      const ReadPlan& pl = plan[r];
+      buf.clear();
+      for (size_t i = pl.c0; i < pl.c1; ++i) buf.push_back(CandLite{cands[i]->se, cands[i]->a.d, cands[i]->a.v, cands[i]->a.chisq, cands[i]->a.lwr});
+      return buf.size();
+    }
+  } src{plan, cands};
+  return emit_placements(pt, rv->nreads, src, names, p, tabular, has_previous, text, len, placements, nplacements, lap);
 }
 
 // As kr_place_batch, for the batch last submitted on `s` with KR_TAP_ACCS, which need not be collected: the tree
@@ -811,33 +826,22 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
   if (res.nreads != nreads) return kr::fail(KR_ERR_ARG, "kr_place_stream: nreads does not match the submitted batch");
   lap("A-C: aggregation, Brent, chi-square on the device + copy back");
   if (res.overflow) return host_path();
-  // candidates in read order, each read's in ascending node number (the order the host path forms them in)
-  std::vector<ReadPlan> plan(nreads);
-  std::vector<size_t> base((size_t)nt + 1, 0);
-  kr::parallel_for(nt, [&](int t) {
-    size_t c = 0;
-    for (size_t r = (size_t)nreads * t / nt; r < (size_t)nreads * (t + 1) / nt; ++r)
-      if (res.rd_info[r] >> 31) c += res.rd_info[r] & 0x3FFFFFFFu;
-    base[(size_t)t + 1] = c;
-  });
-  for (int t = 0; t < nt; ++t) base[(size_t)t + 1] += base[(size_t)t];
-  std::vector<CandLite> cands(base[(size_t)nt]);
-  kr::parallel_for(nt, [&](int t) {
-    size_t at = base[(size_t)t];
-    for (size_t r = (size_t)nreads * t / nt; r < (size_t)nreads * (t + 1) / nt; ++r) {
-      const uint32_t info = res.rd_info[r];
-      if (!(info >> 31)) continue;
-      ReadPlan& pl = plan[r];
-      const uint32_t n = info & 0x3FFFFFFFu, c0 = res.rd_c0[r];
-      pl.reported = true, pl.single = (info >> 30) & 1u;
-      pl.c0 = at, pl.c1 = at + n;
-      for (uint32_t i = 0; i < n; ++i) cands[at + i] = CandLite{res.c_se[c0 + i], res.c_d[c0 + i], res.c_v[c0 + i], res.c_chisq[c0 + i], 1.0};
-      if (n > 1) std::sort(cands.begin() + (ptrdiff_t)at, cands.begin() + (ptrdiff_t)(at + n), [](const CandLite& a, const CandLite& b) { return a.se < b.se; });
-      at += n;
+  // each read's candidates in ascending node number (the order the host path forms them in), straight from the
+  // arrays the device wrote
+  struct DeviceSource {
+    const kr::PlaceDeviceResult& res;
+    bool reported(uint32_t r) const { return (res.rd_info[r] >> 31) != 0; }
+    bool single(uint32_t r) const { return ((res.rd_info[r] >> 30) & 1u) != 0; }
+    size_t fetch(uint32_t r, std::vector<CandLite>& buf) const
+    {
+      const uint32_t n = res.rd_info[r] & 0x3FFFFFFFu, c0 = res.rd_c0[r];
+      buf.clear();
+      for (uint32_t i = 0; i < n; ++i) buf.push_back(CandLite{res.c_se[c0 + i], res.c_d[c0 + i], res.c_v[c0 + i], res.c_chisq[c0 + i], 1.0});
+      if (n > 1) std::sort(buf.begin(), buf.end(), [](const CandLite& a, const CandLite& b) { return a.se < b.se; });
+      return n;
     }
-  });
-  lap("candidates in order");
-  return emit_placements(pt, nreads, plan, cands, names, p, tabular, has_previous, text, len, placements, nplacements, lap);
+  } src{res};
+  return emit_placements(pt, nreads, src, names, p, tabular, has_previous, text, len, placements, nplacements, lap);
 }
 
 uint32_t kr_place_tree_nnodes(const kr_place_tree* pt) { return pt ? pt->t.nnodes() : 0; }
