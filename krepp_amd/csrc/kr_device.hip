@@ -51,6 +51,7 @@
 #include "kr_devutil.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -1118,6 +1119,15 @@ int kr_batch_collect(kr_stream* s, kr_result_view* v)
   HIP_TRY(hipSetDevice(s->ix->device));
   const bool rows_only = (s->flags & KR_ROWS_ONLY) != 0, full = !rows_only;
   const bool pipelined = !s->waited && !s->collected;
+  static const bool timing = getenv("KR_COLLECT_TIMING") != nullptr;
+  auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = timing ? wall() : 0.0;
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const double now = wall();
+    fprintf(stderr, "[collect] %s %.2f ms\n", what, (now - t_mark) * 1e3);
+    t_mark = now;
+  };
   // Lane by lane: as soon as a lane's kernels are done its results start their way to the host on the lane's own
   // stream, while later lanes still compute.  The host arrays are compact (no unused slots between lanes), so a lane's
   // records land behind those of the lanes before it.
@@ -1144,6 +1154,7 @@ int kr_batch_collect(kr_stream* s, kr_result_view* v)
     int rc = kr_batch_wait(s); // (the histogram planes are laid out by the total record count: it must be known first)
     if (rc) return rc;
   }
+  lap("wait for the kernels");
   uint64_t hoff = 0;
   bool copies_started = false;
   if (s->waited) {
@@ -1204,6 +1215,7 @@ int kr_batch_collect(kr_stream* s, kr_result_view* v)
   int rc = kr_batch_wait(s); // (a no-op when it already ran; otherwise every lane is idle by now: aggregates the counters)
   for (uint32_t l = 0; l < s->nlanes; ++l) HIP_TRY(hipStreamSynchronize(s->lanes[l].stream));
   if (rc) return rc;
+  lap("copies to the host");
   // device offsets index the stream's arrays (lane slices); the host arrays are compact
   for (uint32_t l = 0; l < s->nlanes; ++l) {
     const Lane& L = s->lanes[l];
@@ -1230,6 +1242,7 @@ int kr_batch_collect(kr_stream* s, kr_result_view* v)
     for (uint64_t c : part) nrows += c;
     v->nrows = nrows;
   }
+  lap("offsets + row count");
   return KR_OK;
 }
 

@@ -1,0 +1,47 @@
+"""bench.py as the driver runs it, on the GPU box: the one-process default and the N-rank path.  One GPU here, so the
+two ranks share it (--ranks-share-device) and the collective backend is gloo; everything else -- the launcher, rank 0
+building and uploading the index, kr_index_export -> broadcast of every flat buffer -> kr_index_import on the other
+rank, per-rank read shards, MAX-over-ranks timing -- is the code the 8-GPU run executes (there with RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*args):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_gpu():
+    out = run_bench("--gpus", "2", "--backend", "gloo", "--ranks-share-device", "--workload", "toy25", "--reads-per-step", "100000",
+                    "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--check-reads", "3000", "--distinct-batches", "2")
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert len(out["per_rank_reads_per_s"]) == 2 and min(out["per_rank_reads_per_s"]) > 0
+    assert out["index_broadcast"]["bytes"] == out["config"]["index_device_bytes"] > 1e6
+    assert out["check"]["rows_equal"] and out["check"]["max_rel_dist_err"] < 1e-6
+    # whole-job value = reads of both ranks over the slowest rank's time
+    assert out["value"] > 0.9 * min(out["per_rank_reads_per_s"]) and out["value"] <= 2.05 * max(out["per_rank_reads_per_s"])
+
+
+def test_bench_default_line_small():
+    out = run_bench("--workload", "toy25", "--reads-per-step", "200000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "2",
+                    "--check-reads", "3000", "--distinct-batches", "2")
+    assert out["n_gpus"] == 1 and out["unit"] == "reads/s" and out["vs_baseline"] is None
+    rl = out["roofline"]
+    assert rl["bound"] == "hbm" and rl["unit"] == "GB/s" and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-9
+    assert rl["traffic"] is None  # the committed PMC profile is of the 10 GB workload, not of this one
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["value"] > 0
+    assert out["check"]["rows_equal"]
+    hi = out["value_host_inclusive"]
+    assert hi["value"] > 0 and hi["streams"] == 2
