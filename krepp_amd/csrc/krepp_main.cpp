@@ -298,8 +298,10 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
         char* txt = nullptr;
         uint64_t len = 0;
         auto t_dev = now();
+        // dist rows / the summary need (leaf, selected, DIST) only: nothing else is copied back; place keeps its records
+        // on the device; seek also reads the k-mer counts
         int rc = kr_batch_submit(st, j->bases.data() + j->offsets[lo], offs.data(), (uint32_t)(hi - lo),
-                                 KR_BASES_HOST | (place ? KR_TAP_ACCS : 0u));
+                                 KR_BASES_HOST | (place ? KR_TAP_ACCS : (seek ? 0u : KR_ROWS_ONLY)));
         if (!rc) rc = place ? kr_batch_wait(st) : kr_batch_collect(st, &rv); // place: the records stay on the device
         ns_dev += since(t_dev);
         auto t_fmt = now();
