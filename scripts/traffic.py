@@ -29,10 +29,13 @@ req = fetch_b / 64.0
 slotted = "--packed" not in sys.argv  # scripts/profile.sh runs the default (slotted) layout; pass --packed for KR_SLOT_LOG2W=0 runs
 small = 0.0 if slotted else min(req, n * per["probes"])  # isolated descriptor gathers: one request, 64 B each
 lines = req - small
-try:
-    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
-except Exception:
-    commit = None
+import os
+commit = os.environ.get("KR_COMMIT")  # the GPU box has no .git: the caller passes the commit the snapshot was taken at
+if not commit:
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except Exception:
+        commit = None
 out = {
     "kernel": "kr_scan_kernel", "workload": b["config"]["workload"], "table": "slotted" if slotted else "packed",
     "profile": tag, "commit": commit, "scan_ms": b["kernel_ms"]["scan"],
