@@ -111,3 +111,63 @@ def test_syn1000_10gb_index_vs_oracle_and_full_batch_properties(capi, po, synth,
         dx.close()
         hx.close()
         torch.cuda.empty_cache()
+
+
+def test_ten_thousand_genome_index_vs_oracle(capi, po, synth, tmp_path):
+    """The index shape of BASELINE.json configs[3] on one GPU: 10,000 genomes on a Yule tree (default parameters, 2^25 rows;
+    the table inflated to 2 GB to keep the test short -- the 8-GPU run replicates this index per GPU and shards the reads,
+    which changes nothing per GPU).  4,000 reads against the oracle: hits, histograms, rows; then 200,000 reads through the
+    reverse-complement property.  20,000 key slots per wave: the accumulate kernel runs with fewer resident waves and its
+    global-scratch paths are live."""
+    import torch
+
+    n_genomes = 10_000
+    nwk_text = synth.yule_newick(n_genomes, 3)
+    genomes = synth.evolve_genomes(nwk_text, 10_000, seed=3)
+    (tmp_path / "y.nwk").write_text(nwk_text)
+    tsv = synth.write_genomes(genomes, str(tmp_path / "g"))
+    idx = str(tmp_path / "idx")
+    capi.build_index(tsv, idx, nwk=str(tmp_path / "y.nwk"), k=29, w=35, h=13, m=4, r=1, frac=True, num_threads=min(32, os.cpu_count() or 1))
+    hx = capi.HostIndex(idx)
+    dx, (inc, cmer) = synth.inflate_and_upload(torch, capi, hx, torch.device("cuda", 0), 0, 2.0, seed=20260103)
+    try:
+        ox = po.Index(idx)
+        assert ox.info.nleaves == n_genomes
+        ox.replace_table(0, inc, cmer)
+        del inc, cmer
+        n = 4000
+        bases, offs = make_reads(synth, genomes, n, seed=9)
+        ref = ox.dist(bases, offs, None, po.params(collect=3, num_threads=min(32, os.cpu_count() or 1)))
+        st = dx.stream(max_reads=n, max_bases=len(bases), max_records=n * 1024)
+        st.submit(bases, offs, capi.KR_TAP_ACCS | capi.KR_TAP_HITS)
+        res = st.collect()
+        gh, rh = st.hits(), ref["hits"]
+        key = lambda h: np.sort(np.rec.fromarrays([h["read"].astype(np.uint64), h["strand"].astype(np.uint64), h["kpos"].astype(np.uint64),
+                                                   h["cmer_index"].astype(np.uint64), h["hd"].astype(np.uint64), h["se"].astype(np.uint64)]))
+        assert len(gh) == len(rh) > 10 * n and (key(gh) == key(rh)).all()
+        acc = ref["accs"][ref["accs"]["passed"] == 1]
+        want = sorted(zip(acc["read"].tolist(), ((acc["se"] << 1) | acc["strand"]).tolist(), [tuple(x[:5]) for x in acc["hist"].tolist()]))
+        got = sorted(zip(res.rec_read.tolist(), res.rec_key.tolist(), [tuple(x) for x in res.rec_hist.tolist()]))
+        assert got == want
+        assert_rows_close(res.rows(), rows_of_oracle(ref), tol=1e-6)
+        st.close()
+        ox.close()
+        n = 200_000
+        bases, offs = make_reads(synth, genomes, n, seed=10)
+        stf = dx.stream(max_reads=n, max_bases=len(bases), max_records=n * 256)
+
+        def run(b):
+            stf.submit(b, offs)
+            r = stf.collect()
+            sel = r.rec_sel.astype(bool)
+            a = np.stack([r.rec_read[sel].astype(np.uint64), (r.rec_key[sel] >> 1).astype(np.uint64), r.rec_d[sel].view(np.uint64)], axis=1)
+            return a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+
+        rows = run(bases)
+        assert len(rows) > 10 * n
+        assert (run(synth.COMP[bases.reshape(n, 150)[:, ::-1]].reshape(-1)) == rows).all()
+        stf.close()
+    finally:
+        dx.close()
+        hx.close()
+        torch.cuda.empty_cache()
