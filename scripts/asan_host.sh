@@ -1,0 +1,15 @@
+#!/bin/bash
+# AddressSanitizer over the host C++ (reader, builder, placement) with the CPU test suite; the device objects are linked as built.
+# (GPU sanitizers are not available on the pool; this covers what runs on the CPU.)  Restores the normal library afterwards.
+set -e
+cd "$(dirname "$0")/../krepp_amd/csrc"
+mkdir -p /tmp/asan
+for f in kr_host kr_build kr_place; do
+  g++ -std=c++17 -O1 -g -fPIC -fvisibility=hidden -fopenmp -fsanitize=address -fno-omit-frame-pointer -I../../include -I. -c $f.cpp -o /tmp/asan/$f.o
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/asan/libkrepp_amd.so build/kr_device.o build/kr_minimizer.o /tmp/asan/kr_host.o /tmp/asan/kr_build.o /tmp/asan/kr_place.o -lz -lgomp -ldl
+cd ../..
+cp krepp_amd/lib/libkrepp_amd.so /tmp/asan/orig.so
+cp /tmp/asan/libkrepp_amd.so krepp_amd/lib/libkrepp_amd.so
+LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python -m pytest tests -m "not gpu" -x -q -p no:cacheprovider || true
+cp /tmp/asan/orig.so krepp_amd/lib/libkrepp_amd.so
