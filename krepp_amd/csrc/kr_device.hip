@@ -630,8 +630,9 @@ struct kr_stream {
     uint32_t pn = 0, nidx = 0;
     uint32_t *d_parent = nullptr, *d_eff = nullptr, *d_lo = nullptr, *d_idx_to_pt = nullptr;
     uint8_t* d_elig = nullptr;
-    uint32_t *d_len = nullptr, *d_c0 = nullptr, *d_info = nullptr, *d_cse = nullptr, *d_cnt = nullptr;
-    double *d_cd = nullptr, *d_cv = nullptr, *d_cchi = nullptr;
+    uint32_t *d_len = nullptr, *d_c0 = nullptr, *d_info = nullptr, *d_cse = nullptr, *d_cread = nullptr, *d_cnt = nullptr;
+    double *d_cd = nullptr, *d_cv = nullptr, *d_cchi = nullptr, *d_cprob = nullptr, *d_rprob = nullptr;
+    uint64_t cprob_cap = 0, rprob_cap = 0; // doubles
     uint32_t *h_len = nullptr, *h_c0 = nullptr, *h_info = nullptr, *h_cse = nullptr, *h_cnt = nullptr;
     double *h_cd = nullptr, *h_cv = nullptr, *h_cchi = nullptr;
     uint64_t reads_cap = 0, cand_cap = 0, h_cand_cap = 0;
@@ -954,7 +955,8 @@ void kr_stream_destroy(kr_stream* s)
   {
     kr_stream::PlaceWs& w = s->pw;
     for (void* p : {(void*)w.d_parent, (void*)w.d_eff, (void*)w.d_lo, (void*)w.d_idx_to_pt, (void*)w.d_elig, (void*)w.d_len, (void*)w.d_c0,
-                    (void*)w.d_info, (void*)w.d_cse, (void*)w.d_cnt, (void*)w.d_cd, (void*)w.d_cv, (void*)w.d_cchi})
+                    (void*)w.d_info, (void*)w.d_cse, (void*)w.d_cread, (void*)w.d_cnt, (void*)w.d_cd, (void*)w.d_cv, (void*)w.d_cchi, (void*)w.d_cprob,
+                    (void*)w.d_rprob})
       if (p) (void)hipFree(p);
     for (void* p : {(void*)w.h_len, (void*)w.h_c0, (void*)w.h_info, (void*)w.h_cse, (void*)w.h_cnt, (void*)w.h_cd, (void*)w.h_cv, (void*)w.h_cchi})
       if (p) (void)hipHostFree(p);
@@ -1351,19 +1353,32 @@ int kr::place_on_device(kr_stream* s, const void* tree_tag, const kr::PlaceTreeA
   { // candidate slots: every leaf and every distinct ancestor of a read may be one; a batch that needs more reports it
     const uint64_t want = std::max<uint64_t>(1u << 20, (uint64_t)n * 24);
     if (want > w.cand_cap) {
-      if ((rc = dev_renew(w.d_cse, want)) || (rc = dev_renew(w.d_cd, want)) || (rc = dev_renew(w.d_cv, want)) || (rc = dev_renew(w.d_cchi, want))) return rc;
+      if ((rc = dev_renew(w.d_cse, want)) || (rc = dev_renew(w.d_cread, want)) || (rc = dev_renew(w.d_cd, want)) || (rc = dev_renew(w.d_cv, want)) ||
+          (rc = dev_renew(w.d_cchi, want)))
+        return rc;
       w.cand_cap = want;
+    }
+    const uint64_t np_ = s->dp.np;
+    if (w.cand_cap * (np_ + 2) > w.cprob_cap) {
+      if ((rc = dev_renew(w.d_cprob, w.cand_cap * (np_ + 2)))) return rc;
+      w.cprob_cap = w.cand_cap * (np_ + 2);
+    }
+    if (w.reads_cap * (np_ + 3) > w.rprob_cap) {
+      if ((rc = dev_renew(w.d_rprob, w.reads_cap * (np_ + 3)))) return rc;
+      w.rprob_cap = w.reads_cap * (np_ + 3);
     }
   }
   memcpy(w.h_len, read_len, (uint64_t)n * 4);
   HIP_TRY(hipMemcpyAsync(w.d_len, w.h_len, (uint64_t)n * 4, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(w.d_cnt, 0, 16, st));
+  HIP_TRY(hipMemsetAsync(w.d_cse, 0, w.cand_cap * 4, st)); // 0 = unused slot: what the second kernel and the host skip
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, s->device));
   PlaceTree PT{w.d_parent, w.d_eff, w.d_elig, w.d_lo, w.d_idx_to_pt, T.pn, T.nidx};
-  PlaceOut PO{w.d_c0, w.d_info, w.d_cse, w.d_cd, w.d_cv, w.d_cchi, w.d_cnt, (uint32_t)std::min<uint64_t>(w.cand_cap, 0xFFFFFFFFu)};
-  const uint32_t grid = std::min<uint32_t>(n, (uint32_t)prop.multiProcessorCount * 12u);
+  PlaceOut PO{w.d_c0, w.d_info, w.d_cse, w.d_cread, w.d_cd, w.d_cv, w.d_cchi, w.d_cprob, w.d_rprob, w.d_cnt, (uint32_t)std::min<uint64_t>(w.cand_cap, 0x3FFFFFFFu)};
+  const uint32_t grid = std::min<uint32_t>(n, (uint32_t)prop.multiProcessorCount * 16u);
   hipLaunchKernelGGL(kr_place_kernel, dim3(grid), dim3(kWave), 0, st, s->llh, s->ix->dix, s->out, n, w.d_len, PT, PO, tau, no_filter ? 1u : 0u);
+  hipLaunchKernelGGL(kr_place_llh_kernel, dim3((uint32_t)prop.multiProcessorCount * 8u), dim3(256), 0, st, s->llh, PO);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(w.h_cnt, w.d_cnt, 16, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(w.h_c0, w.d_c0, (uint64_t)n * 4, hipMemcpyDeviceToHost, st));

@@ -836,7 +836,8 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
     {
       const uint32_t n = res.rd_info[r] & 0x3FFFFFFFu, c0 = res.rd_c0[r];
       buf.clear();
-      for (uint32_t i = 0; i < n; ++i) buf.push_back(CandLite{res.c_se[c0 + i], res.c_d[c0 + i], res.c_v[c0 + i], res.c_chisq[c0 + i], 1.0});
+      for (uint32_t i = 0; i < n; ++i) // (0x7FFFFFFF: node 0 of a single placement -- 0 itself marks an unused slot on the device)
+        buf.push_back(CandLite{res.c_se[c0 + i] == 0x7FFFFFFFu ? 0u : res.c_se[c0 + i], res.c_d[c0 + i], res.c_v[c0 + i], res.c_chisq[c0 + i], 1.0});
       if (n > 1) std::sort(buf.begin(), buf.end(), [](const CandLite& a, const CandLite& b) { return a.se < b.se; });
       return n;
     }
