@@ -596,7 +596,7 @@ class Placer:
         self.lib.kr_free(txt)
         return s
 
-    def place(self, bases, offsets, names, host=False, c_names=None):
+    def place(self, bases, offsets, names, host=False, c_names=None, want_placements=True):
         """One batch.  host=False: kr_place_stream (tree aggregation and likelihoods on the device);
         host=True: kr_batch_collect + kr_place_batch (aggregation on the host).  Same output."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
@@ -608,11 +608,12 @@ class Placer:
             rv = KrResultView()
             check(self.lib.kr_batch_collect(self.st.h, C.byref(rv)))
             check(self.lib.kr_place_batch(self.hx.h, self.dx.h, self.pt, C.byref(rv), offsets.ctypes.data, arr, C.byref(self.popts),
-                                          int(self.tabular), C.byref(self.prev), C.byref(txt), C.byref(ln), C.byref(pls), C.byref(npl)))
+                                          int(self.tabular), C.byref(self.prev), C.byref(txt), C.byref(ln),
+                                          C.byref(pls) if want_placements else None, C.byref(npl) if want_placements else None))
         else:
             check(self.lib.kr_place_stream(self.hx.h, self.dx.h, self.pt, self.st.h, len(offsets) - 1, offsets.ctypes.data, arr,
                                            C.byref(self.popts), int(self.tabular), C.byref(self.prev), C.byref(txt), C.byref(ln),
-                                           C.byref(pls), C.byref(npl)))
+                                           C.byref(pls) if want_placements else None, C.byref(npl) if want_placements else None))
         text = C.string_at(txt, ln.value).decode()
         pl = (np.frombuffer(C.string_at(pls, npl.value * PLACEMENT_DT.itemsize), dtype=PLACEMENT_DT).copy()
               if npl.value else np.zeros(0, PLACEMENT_DT))

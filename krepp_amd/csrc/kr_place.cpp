@@ -394,9 +394,17 @@ int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
     }
     o.append(b, kr::fmt_fixed5(v, b));
   };
+  auto unum = [](std::string& o, uint32_t v) { // decimal, no allocation
+    char b[12];
+    int n = 0;
+    do b[n++] = (char)('0' + v % 10u), v /= 10u;
+    while (v);
+    while (n) o += b[--n];
+  };
+  const bool want_pl = placements && nplacements;
   auto jfields = [&](std::string& o, uint32_t q, const CandLite& a) {
     o += '[';
-    o += std::to_string(en(q));
+    unum(o, en(q));
     o += ", ", num(o, a.jc() - mid(q));
     o += ", ", num(o, mid(q));
     o += ", ", num(o, -a.v);
@@ -406,9 +414,12 @@ int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
   };
   auto tfields = [&](std::string& o, uint32_t q, const CandLite& a) {
     const std::string& nm = pt->t.nodes[q].label;
-    o += nm.empty() ? std::string("NA") : nm;
+    if (nm.empty())
+      o += "NA";
+    else
+      o += nm;
     o += '\t';
-    o += std::to_string(en(q));
+    unum(o, en(q));
     o += '\t', num(o, a.lwr);
     o += '\t', num(o, a.d);
   };
@@ -421,6 +432,7 @@ int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
     std::vector<kr_placement>& pls = ppls[(size_t)t];
     bool prev = false; // within the piece; pieces are joined with the separator below
     auto record = [&](uint32_t r, uint32_t q, const CandLite& a) {
+      if (!want_pl) return; // (--summarize and library callers ask for the placements; the text modes of the CLI do not)
       kr_placement x;
       x.read = r, x.edge = en(q), x.lwr = a.lwr, x.d_llh = a.d, x.v_llh = a.v, x.pendant = a.jc() - mid(q), x.distal = mid(q);
       pls.push_back(x);
@@ -428,7 +440,7 @@ int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
     std::vector<size_t> nd_v;
     std::vector<CandLite> cands; // the read's candidates
     out.reserve((size_t)(rb - ra) * (jp ? 160 : tb ? 72 : 0) + 64);
-    pls.reserve((size_t)(rb - ra) * 2);
+    if (want_pl) pls.reserve((size_t)(rb - ra) * 2);
     for (uint32_t r = ra; r < rb; ++r) {
       if (!src.reported(r)) continue;
       struct { bool single; size_t c0, c1; } pl{src.single(r), 0, 0};

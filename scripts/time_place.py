@@ -34,7 +34,7 @@ for tab in (0, 1, 2):
     arr = (C.c_char_p * len(names))(*[x.encode() for x in names])
     for host in (True, False):
         t = time.time()
-        text, p = pl.place(b, o, names, host=host, c_names=arr)
+        text, p = pl.place(b, o, names, host=host, c_names=arr, want_placements=(tab == 2))
         dt = time.time() - t
         print(f"  {'host' if host else 'device'} back end, submit to text: {n} reads in {dt:.3f} s = {n / dt / 1e6:.2f} M reads/s")
     tm = pl.st.timing()
