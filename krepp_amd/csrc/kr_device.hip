@@ -85,7 +85,7 @@ namespace {
 uint32_t probe_lds_bytes(uint32_t np, uint32_t bm_words, bool lean = false)
 {
   if (lean) // single-segment instantiation: short stack (bitmap aliases it) | key slots | event region
-    return (lean_stack_bytes(bm_words) + kLdsSlots * 4 + kLdsSlots * np * (kPlaneWords + 1) * 4 + 15u) & ~15u;
+    return (lean_stack_bytes(bm_words) + kLdsSlots * 4 + lean_ev_words(np) * 4 + 15u) & ~15u;
   uint32_t b = kStackCap * 8;
   b += kLdsSlots * 4 + kLdsSlots * np * kPlaneWords * 4 + kLdsSlots * np * 4 + 2 * bm_words * 4 + bm_words; // two bitmaps + u16 prefix per 2 words
   if (getenv("KR_DEBUG_LDS_PAD")) b += (uint32_t)atoi(getenv("KR_DEBUG_LDS_PAD")); // occupancy experiments
@@ -839,7 +839,7 @@ int kr_stream_create(const kr_index* ix, const kr_params* p, uint32_t max_reads,
     return kr::fail(KR_ERR_ARG, "kr_stream_create: this many reference leaves with this --hdist-th needs more LDS than a workgroup has");
   uint32_t per_cu = std::min<uint32_t>(16u, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words));
   // the single-segment instantiation has a lean LDS layout and 96 registers: 5 waves per SIMD
-  uint32_t per_cu_lean = std::min<uint32_t>(20u, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words, true));
+  uint32_t per_cu_lean = std::min<uint32_t>(4u * KR_ACC_LEAN_WPE, 163840u / probe_lds_bytes(p->hdist_th + 1, bm_words, true));
   if (getenv("KR_DEBUG_ACC_WAVES")) {
     per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(getenv("KR_DEBUG_ACC_WAVES")));
     per_cu_lean = std::min<uint32_t>(per_cu_lean, (uint32_t)atoi(getenv("KR_DEBUG_ACC_WAVES")));
