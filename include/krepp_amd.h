@@ -163,6 +163,8 @@ typedef struct kr_stream kr_stream;
  * max_records bounds the (read, strand, leaf) accumulators one batch may emit
  * (0 = default: max_reads * min(16, max(8, tree nodes + 1))); a batch that needs more
  * fails with KR_ERR_CAPACITY and can be resubmitted in smaller pieces. */
+/* Kernels of all streams created on one kr_index run one batch after the other in submission order (a per-index
+ * event chain); copies to and from the host overlap them.  Use two streams in turn to keep the GPU busy. */
 KR_API int kr_stream_create(const kr_index*, const kr_params*, uint32_t max_reads, uint64_t max_bases,
                             uint64_t max_records, kr_stream** out);
 KR_API void kr_stream_destroy(kr_stream*);
@@ -213,9 +215,13 @@ typedef struct kr_result_view {
   uint64_t nrows;             /* number of rec_sel == 1                                  */
 } kr_result_view;
 
-/* Waits for the batch and copies results to pinned host memory owned by the stream. */
+/* Waits for the batch and copies results to pinned host memory owned by the stream (lane by lane: a lane's
+ * results travel while later lanes still compute).  Host view: records are compact, a read's records are
+ * [read_off, read_off + read_cnt) in ascending key order; the order of the reads' record groups in the arrays
+ * is not the read order (record slots are handed out to waves in chunks) and may differ from run to run. */
 KR_API int kr_batch_collect(kr_stream*, kr_result_view* out);
-/* As above but the arrays stay in HBM (device pointers); only counts are read back. */
+/* As above but the arrays stay in HBM (device pointers); only counts are read back.  Device view: `nrecs` is
+ * the extent of record slots handed out, unused slots (rec_key == 0) included; always go through read_off / read_cnt. */
 KR_API int kr_batch_collect_device(kr_stream*, kr_result_view* out);
 
 /* Debug taps (parity tests).  Hits: one entry per table entry with hd <= hdist_th. */

@@ -24,7 +24,9 @@ with open(fq, "wb") as f:
         f.write(b"".join(rows))
         done += m
 exe = os.path.join(root, "krepp_amd", "lib", "krepp")
-for sub, extra, env in (("dist", [], {}), ("dist", [], {"KR_CLI_WORKERS_PER_GPU": "3"}), ("dist", ["--summarize"], {}),
+for sub, extra, env in (("dist", [], {}), ("dist", [], {"KR_CLI_WORKERS_PER_GPU": "3"}), ("dist", [], {"KR_CLI_BATCH_READS": "262144"}),
+                        ("dist", [], {"KR_CLI_BATCH_READS": "262144", "KR_CLI_WORKERS_PER_GPU": "3"}),
+                        ("dist", [], {"KR_CLI_BATCH_READS": "1048576", "KR_CLI_WORKERS_PER_GPU": "3"}), ("dist", ["--summarize"], {}),
                         ("place", [], {}), ("place", ["--tabular"], {}), ("place", ["--summarize"], {})):
     t = time.time()
     r = subprocess.run([exe, sub, "-i", idx, "-q", fq, "-o", os.path.join(work, "out.txt")] + extra, capture_output=True, text=True,
