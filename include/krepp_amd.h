@@ -171,7 +171,7 @@ KR_API void kr_stream_destroy(kr_stream*);
 
 #define KR_BASES_HOST 0u
 #define KR_BASES_DEVICE 1u /* bases/offsets already resident in this device's HBM */
-#define KR_TAP_ACCS 2u     /* keep per-(read,strand,leaf) histograms for kr_batch_taps */
+#define KR_TAP_ACCS 2u     /* keep every (read,strand,leaf) histogram: rec_hist of the views, `place` */
 #define KR_TAP_HITS 4u     /* record every table hit (debug; slow; the batch runs as one lane) */
 #define KR_BASES_PINNED 8u /* host `bases` AND `offsets` are page-locked (hipHostMalloc / hipHostRegister, */
                            /* e.g. kr_host_alloc): copied to the device straight from the caller's       */

@@ -1048,6 +1048,7 @@ int kr_batch_submit(kr_stream* s, const uint8_t* bases, const uint64_t* offsets,
     o.rec_read += rb, o.rec_key += rb, o.rec_hist += rb, o.rec_d += rb, o.rec_v += rb, o.rec_chisq += rb, o.rec_sel += rb;
     o.rec_w0 += rb, o.rec_rep += rb, o.rep_list += rb, o.rep_dv += rb;
     o.rec_cap = lane_rec_cap;
+    o.hist_always = (flags & KR_TAP_ACCS) ? 1u : 0u; // else a record's planes exist only where its packed word cannot describe it
     int rc = launch_lane(s, L, flags);
     if (rc) return rc;
   }
@@ -1313,6 +1314,8 @@ int kr::place_on_device(kr_stream* s, const void* tree_tag, const kr::PlaceTreeA
                         bool no_filter, kr::PlaceDeviceResult* out)
 {
   if (!s || !out || !read_len || !T.parent || !T.eff || !T.elig || !T.lo || !T.idx_to_pt) return kr::fail(KR_ERR_ARG, "place_on_device: null argument");
+  if (!s->submitted || !(s->flags & KR_TAP_ACCS))
+    return kr::fail(KR_ERR_STATE, "place: the batch must be submitted with KR_TAP_ACCS (the back end reads every record's histogram)");
   int rc = kr_batch_wait(s);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(s->device));
