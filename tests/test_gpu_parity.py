@@ -211,6 +211,21 @@ def test_long_reads_and_ragged_batches(capi, po, toy, toy_genomes):
     assert got == want
     assert_rows_close(res.rows(), rows_of_oracle(ref))
     assert sorted(st.format_dist(hx, names).splitlines()) == sorted(ref["text"].splitlines())
+    # without KR_TAP_ACCS a record is its key and the packed problem word only (no histogram planes, no read index): the
+    # likelihood and selection kernels decode the word -- default, --filter (chi-square from the closest leaf's word),
+    # --no-multi, another threshold (no word: planes are written), and the same through two lanes
+    for pkw, okw in ((dict(), dict()), (dict(no_filter=0), dict(no_filter=0)), (dict(multi=0), dict(multi=0)), (dict(hdist_th=3), dict(hdist_th=3))):
+        want_rows = rows_of_oracle(ox.dist(bases, offs, names, po.params(collect=0, **okw)))
+        _, r0 = gpu_dist(capi, dx, bases, offs, 0, **pkw)
+        assert_rows_close(r0.rows(), want_rows)
+        assert r0.rec_hist is None
+    os.environ["KR_LANE_MIN_READS"], os.environ["KR_LANES"] = "4", "2"
+    try:
+        stl, rl = gpu_dist(capi, dx, bases, offs, 0, no_filter=0)
+        assert stl.timing().lanes == 2
+        assert_rows_close(rl.rows(), rows_of_oracle(ox.dist(bases, offs, names, po.params(collect=0, no_filter=0))))
+    finally:
+        os.environ.pop("KR_LANE_MIN_READS"), os.environ.pop("KR_LANES")
 
 
 @pytest.mark.parametrize("slot_log2w,dbg", [("0", "8192"), ("5", "8192"), ("6", "8192"), ("6", "0")])
