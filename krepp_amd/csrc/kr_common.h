@@ -39,6 +39,7 @@ void balanced_tree(const std::vector<std::string>& names, HostTree& out);
 // runs pieces too; returns when all are done.
 void parallel_for(int n, const std::function<void(int)>& f);
 int parallel_width(); // threads worth asking for (pool size + 1)
+unsigned usable_cpus(); // hardware threads this process may run on, capped by the cgroup CPU quota
 
 // MurmurHash3_x86_32 based 64-bit name hash (src/record.hpp:26-36)
 uint64_t leaf_name_hash(const std::string& name);

@@ -12,6 +12,8 @@
 //   report text                      src/query.cpp:152-196, src/query.hpp:210
 #include "kr_common.h"
 
+#include <sched.h>
+
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -287,6 +289,40 @@ void balanced_tree(const std::vector<std::string>& names, HostTree& out)
 // kr_host_index
 // ---------------------------------------------------------------------------
 namespace kr {
+// CPUs this process may actually use: the hardware threads it is allowed on, capped by the cgroup CPU quota (a container
+// can see 256 hardware threads and be granted 16 CPUs' worth of time: a pool sized by the former is throttled by the
+// scheduler in the middle of its work)
+unsigned usable_cpus()
+{
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+  auto quota = [&](const char* path_max, const char* path_quota, const char* path_period) {
+    if (FILE* f = fopen(path_max, "r")) { // cgroup v2: "<quota|max> <period>"
+      char q[64] = {0};
+      long long per = 0;
+      if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) {
+        const long long qq = atoll(q);
+        if (qq > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (qq + per - 1) / per));
+      }
+      fclose(f);
+      return;
+    }
+    long long qq = -1, per = 0; // cgroup v1
+    if (FILE* f = fopen(path_quota, "r")) {
+      if (fscanf(f, "%lld", &qq) != 1) qq = -1;
+      fclose(f);
+    }
+    if (FILE* f = fopen(path_period, "r")) {
+      if (fscanf(f, "%lld", &per) != 1) per = 0;
+      fclose(f);
+    }
+    if (qq > 0 && per > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (qq + per - 1) / per));
+  };
+  quota("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+  return n;
+}
+
 namespace {
 struct Pool {
   struct Call {
@@ -301,7 +337,9 @@ struct Pool {
   Pool()
   {
     const char* e = getenv("KR_HOST_THREADS");
-    unsigned nt = e ? (unsigned)atoi(e) : std::min(31u, std::max(1u, std::thread::hardware_concurrency() / 4));
+    // the caller works too (parallel_width = pool + 1): one thread per usable CPU, at most 32 in all
+    const unsigned cpus = kr::usable_cpus();
+    unsigned nt = e ? (unsigned)atoi(e) : std::min(31u, std::max(1u, cpus > 1 ? cpus - 1 : 1u));
     for (unsigned t = 0; t < nt; ++t) threads.emplace_back([this] { run(); });
   }
   ~Pool()
@@ -1273,7 +1311,7 @@ int kr_fastx_open(const char* path, kr_fastx** out)
   {
     const char* et = getenv("KR_FASTX_THREADS");
     const char* em = getenv("KR_FASTX_PAR_MIN");
-    unsigned nt = et ? (unsigned)atoi(et) : std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    unsigned nt = et ? (unsigned)atoi(et) : std::min(8u, std::max(1u, kr::usable_cpus() / 2));
     const uint64_t par_min = em ? strtoull(em, nullptr, 10) : (32ull << 20);
     struct stat sb;
     const bool regular = nt && stat(path, &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size >= par_min; // never a pipe
