@@ -397,6 +397,23 @@ def test_device_entry_points_fail_loudly_without_gpu(capi, toy_index_dir):
     assert e.value.code == capi.KR_ERR_NO_DEVICE
 
 
+def test_round2_entry_points_reject_bad_arguments_without_gpu(capi):
+    """kr_index_broadcast / kr_place_stream / kr_batch_* check their arguments before anything touches a device."""
+    import ctypes as C
+    lib = capi.load()
+    outs = (C.c_void_p * 1)()
+    devs = (C.c_int * 1)(0)
+    assert lib.kr_index_broadcast(None, 1, devs, outs) == capi.KR_ERR_ARG
+    assert b"kr_index_broadcast" in lib.kr_last_error()
+    txt, ln = C.c_void_p(), C.c_uint64()
+    prev = C.c_int(0)
+    p = capi.default_params()
+    assert lib.kr_place_stream(None, None, None, None, 1, None, None, C.byref(p), 0, C.byref(prev), C.byref(txt), C.byref(ln), None, None) == capi.KR_ERR_ARG
+    assert lib.kr_batch_wait(None) == capi.KR_ERR_STATE
+    assert lib.kr_batch_submit(None, None, None, 1, 0) == capi.KR_ERR_ARG
+    lib.kr_host_free(None)  # a no-op
+
+
 def test_cli_usage_errors(capi):
     exe = os.path.join(ROOT, "krepp_amd", "lib", "krepp")
     r = subprocess.run([exe, "seek"], capture_output=True, text=True)
