@@ -625,6 +625,41 @@ def test_export_import_of_a_slotted_index(capi, po, synth, tmp_path, monkeypatch
     assert_rows_close(b.rows(), rows_of_oracle(ref))
 
 
+def test_occupancy_bitmap_of_a_sparse_table(capi, po, synth, tmp_path, monkeypatch):
+    """A small index in a large table (2^21 rows, most of them empty) carries a one-bit-per-row occupancy bitmap that the
+    scan consults before it fetches a bucket descriptor: same hits and rows with and without it, and the replica of
+    such an index (export / import / RCCL broadcast) receives the bitmap."""
+    nwk = "((a:0.03,b:0.03):0.02,(c:0.05,(d:0.01,e:0.01):0.02):0.01);"
+    g = synth.evolve_genomes(nwk, 60_000, seed=12)
+    tsv = synth.write_genomes(g, str(tmp_path / "g"))
+    (tmp_path / "t.nwk").write_text(nwk)
+    idx = str(tmp_path / "ix")
+    capi.build_index(tsv, idx, nwk=str(tmp_path / "t.nwk"), k=27, w=35, h=11, m=4, r=1, frac=True, num_threads=4)
+    bases, offs, rn = synth.sample_reads(g, 2000, seed=3)
+    ref = po.Index(idx).dist(bases, offs, rn, po.params(collect=2))
+    hx = capi.HostIndex(idx)
+    out = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("KR_OCC_BITMAP", v)
+        dx = hx.upload(0)
+        st, res = gpu_dist(capi, dx, bases, offs, capi.KR_TAP_HITS)
+        h = st.hits()
+        out[v] = (sorted(zip(h["read"].tolist(), h["strand"].tolist(), h["kpos"].tolist(), h["cmer_index"].tolist(), h["hd"].tolist())), res.rows(), dx.device_bytes)
+        if v == "1":
+            (rep,) = dx.broadcast([0])
+            assert rep.device_bytes == dx.device_bytes
+            _, rr = gpu_dist(capi, rep, bases, offs)
+            assert rr.rows() == res.rows()
+            rep.close()
+        st.close()
+        dx.close()
+    assert out["0"][0] == out["1"][0] and out["0"][1] == out["1"][1] and len(out["1"][0]) > 10_000
+    assert out["1"][2] == out["0"][2] + (1 << 21) // 8  # the bitmap: one bit per row
+    rh = ref["hits"]
+    assert out["1"][0] == sorted(zip(rh["read"].tolist(), rh["strand"].tolist(), rh["kpos"].tolist(), rh["cmer_index"].tolist(), rh["hd"].tolist()))
+    assert_rows_close(out["1"][1], rows_of_oracle(ref))
+
+
 def test_cli_dist_end_to_end(capi, po, toy_index_dir, toy_reads, tmp_path):
     """BASELINE.json configs[0] plumbing: the `krepp dist` binary on an index directory and a FASTQ
     file; stdout must be the reference's header plus the oracle's rows (input order, 5 decimals)."""
