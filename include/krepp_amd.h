@@ -208,7 +208,7 @@ typedef struct kr_result_view {
   const uint8_t* rec_sel;     /* [nrecs]  1 = this record is an output row of `dist`     */
   const double* rec_d;        /* [nrecs]  d_llh                                          */
   const double* rec_v;        /* [nrecs]  v_llh                                          */
-  const double* rec_chisq;    /* [nrecs]  chi-square vs the closest (filter mode), else NaN */
+  const double* rec_chisq;    /* [nrecs]  chi-square vs the closest (filter mode), else NaN (NULL in a device view) */
   const uint32_t* rec_hist;   /* with KR_TAP_ACCS, else NULL: hist[x] of record i at      */
                               /* rec_hist[x * rec_hist_stride + i], x = 0..hdist_th       */
   uint64_t rec_hist_stride;

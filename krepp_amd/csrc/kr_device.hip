@@ -55,6 +55,7 @@
 #include "kr_devutil.h"
 
 #include <algorithm>
+#include <limits>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
