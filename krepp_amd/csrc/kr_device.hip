@@ -20,9 +20,9 @@
 //   kr_llh_kernel        one lane per distinct problem, lanes refilled as their minimisations converge:
 //                        Brent minimisation of HDistHistLLH in fp64 [src/hdhistllh.hpp:51-96,
 //                        src/query.cpp:426-433, boost::math::tools::brent_find_minima].
-//   kr_llh_copy_kernel   (d, v) of its problem to every record.
-//   kr_select_kernel     32 lanes per read, one record per lane: strand merge, closest reference, --filter /
-//                        --dist-max / --no-multi selection [src/query.cpp:96-139,158-196].
+//   kr_select_kernel     32 lanes per read, one record per lane: (d, v) of its problem to every record, then strand
+//                        merge, closest reference, --filter / --dist-max / --no-multi selection
+//                        [src/query.cpp:96-139,158-196].
 //
 // Exactness: Minfo::update_match counts, per read position, only the smallest Hamming
 // distance among all hits that reach a leaf.  Here a hit sets bit `pos` in plane `hd` of

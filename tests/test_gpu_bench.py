@@ -44,4 +44,4 @@ def test_bench_default_line_small():
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["value"] > 0
     assert out["check"]["rows_equal"]
     hi = out["value_host_inclusive"]
-    assert hi["value"] > 0 and hi["streams"] == 2
+    assert hi["value"] > 0 and hi["streams"] == 3
