@@ -55,6 +55,7 @@
 #include "kr_devutil.h"
 
 #include <algorithm>
+#include <iterator>
 #include <limits>
 #include <chrono>
 #include <cmath>

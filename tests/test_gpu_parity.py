@@ -380,7 +380,7 @@ def test_large_clade_colours_spill_the_work_stack(capi, po, synth, tmp_path):
     """3,000 nearly identical genomes: almost every k-mer carries the colour of a clade of hundreds to thousands of
     leaves.  Walking such a colour through its parts fans out faster than the 64-wide pops consume it; the work stack
     (192 / 256 entries of LDS) moves its older half to global memory instead of giving up (before: KR_ERR_CAPACITY).  Since
-    round 2 a clade is a run of leaf ranks and is not walked at all: both forms of the index are checked."""
+    round 2 a clade is a run of leaf ranks (a "flat" colour) and is not walked at all: both forms of the index are checked."""
     n = 3000
     nwk = synth.yule_newick(n, 9, mean_blen=0.0003)
     g = synth.evolve_genomes(nwk, 500, seed=5)
@@ -389,12 +389,12 @@ def test_large_clade_colours_spill_the_work_stack(capi, po, synth, tmp_path):
     idx = str(tmp_path / "ix")
     capi.build_index(tsv, idx, nwk=str(tmp_path / "t.nwk"), k=29, w=33, h=13, m=2, r=0, frac=True, num_threads=8)
     hx = capi.HostIndex(idx)
-    dx = hx.upload(0)  # clades of 8 or more consecutive leaf ranks are "run" colours: one gather, no walk, no fan-out
-    os.environ["KR_RUN_MIN"] = "0"  # ... and the same index with every colour walked through its parts: the stack spills
+    dx = hx.upload(0)  # a clade is a "flat" colour (a run of leaf ranks): one gather, no walk, no fan-out
+    os.environ["KR_FLAT_MAX"] = "0"  # ... and the same index with every colour walked through its parts: the stack spills
     try:
         dx_walk = hx.upload(0)
     finally:
-        del os.environ["KR_RUN_MIN"]
+        del os.environ["KR_FLAT_MAX"]
     ox = po.Index(idx)
     spills = 0
     for dx, length, dbg, nreads in ((dx, 150, "0", 120), (dx, 150, "8", 40), (dx, 300, "0", 40), (dx, 300, "8192", 40),
