@@ -393,12 +393,16 @@ def test_large_clade_colours_spill_the_work_stack(capi, po, synth, tmp_path):
     os.environ["KR_FLAT_MAX"] = "0"  # ... and the same index with every colour walked through its parts: the stack spills
     try:
         dx_walk = hx.upload(0)
+        os.environ["KR_FLAT_MAX"] = "4"  # ... and with lists of at most 4 leaves: walked colours whose parts are runs and lists
+        dx_mix = hx.upload(0)
     finally:
         del os.environ["KR_FLAT_MAX"]
+    assert dx.device_bytes > dx_mix.device_bytes > dx_walk.device_bytes  # (the leaf lists)
     ox = po.Index(idx)
     spills = 0
     for dx, length, dbg, nreads in ((dx, 150, "0", 120), (dx, 150, "8", 40), (dx, 300, "0", 40), (dx, 300, "8192", 40),
-                                    (dx_walk, 150, "0", 120), (dx_walk, 150, "8", 40), (dx_walk, 300, "0", 40), (dx_walk, 300, "8192", 40)):
+                                    (dx_walk, 150, "0", 120), (dx_walk, 150, "8", 40), (dx_walk, 300, "0", 40), (dx_walk, 300, "8192", 40),
+                                    (dx_mix, 150, "0", 120), (dx_mix, 300, "0", 40)):
         bases, offs, rn = synth.sample_reads(g, nreads, seed=3 + length, length=length)
         ref = ox.dist(bases, offs, rn, po.params(collect=7, num_threads=8))
         acc = ref["accs"][ref["accs"]["passed"] == 1]
