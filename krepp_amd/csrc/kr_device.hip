@@ -20,7 +20,7 @@
 //   kr_llh_kernel        one lane per distinct problem, lanes refilled as their minimisations converge:
 //                        Brent minimisation of HDistHistLLH in fp64 [src/hdhistllh.hpp:51-96,
 //                        src/query.cpp:426-433, boost::math::tools::brent_find_minima].
-//   kr_select_kernel     32 lanes per read, one record per lane: (d, v) of its problem to every record, then strand
+//   kr_select_kernel     a wave per read, one record per lane: (d, v) of its problem to every record, then strand
 //                        merge, closest reference, --filter / --dist-max / --no-multi selection
 //                        [src/query.cpp:96-139,158-196].
 //
