@@ -246,6 +246,14 @@ KR_API int kr_batch_readtaps(kr_stream*, const kr_readtap** taps);
 KR_API int kr_debug_front_end(const kr_index*, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads,
                               uint32_t stride, uint32_t* rix, uint32_t* enc32, uint8_t* valid, uint8_t* pass);
 
+/* The host pass of kr_index_upload over a library's colour table (no device needed): the tagged form of every colour id
+ * (class in the top two bits: 0 drop, 1 leaf rank, 2 walk through se_to_pse, 3 flat), the se_to_pse table as the device holds it
+ * ({part, part} tagged, or for a flat colour {base | list flag << 31, count}) and the leaf lists.  node_kind[se], se <= tree_nnodes:
+ * 0 null, 1 leaf, 2 internal (as in kr_index_view).  *nlist: in = capacity of lists_out in entries, out = entries needed.
+ * Replaces the per-hit walk of src/query.cpp:369-387 for the colours whose leaves can be named at upload. */
+KR_API int kr_debug_colour_classes(const uint32_t* pse_pairs /*[2*nsubsets]*/, uint32_t nsubsets, const uint8_t* node_kind, uint32_t tree_nnodes,
+                                   uint32_t* cls_out /*[nsubsets]*/, uint32_t* pse_out /*[2*nsubsets]*/, uint32_t* lists_out, uint64_t* nlist);
+
 /* Likelihood + minimiser on their own (device): one problem per element. */
 KR_API int kr_debug_brent(const kr_index*, uint32_t hdist_th, uint32_t n, const uint32_t* hist /*[n*(th+1)]*/,
                           const uint32_t* onmers, const double* rho, double* d_out, double* v_out);

@@ -87,7 +87,7 @@ EXPORTS = [
     "kr_index_upload", "kr_index_free", "kr_index_export", "kr_index_import", "kr_index_device_bytes", "kr_index_broadcast",
     "kr_params_default", "kr_stream_create", "kr_stream_destroy", "kr_batch_submit", "kr_batch_wait",
     "kr_batch_collect", "kr_batch_collect_device", "kr_batch_hits", "kr_batch_readtaps",
-    "kr_debug_front_end", "kr_debug_brent", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
+    "kr_debug_front_end", "kr_debug_brent", "kr_debug_colour_classes", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
     "kr_place_tree_create", "kr_place_tree_create_lineage", "kr_place_tree_nnodes", "kr_place_summary_add",
     "kr_place_summary_text", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_stream", "kr_place_frame",
     "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_format_dist", "kr_free", "kr_host_alloc", "kr_host_free",
@@ -148,6 +148,7 @@ def load():
     lib.kr_batch_readtaps.argtypes = [vp, C.POINTER(u32p)]
     lib.kr_debug_front_end.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     lib.kr_debug_brent.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]
+    lib.kr_debug_colour_classes.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, vp, vp, C.POINTER(C.c_uint64)]
     lib.kr_batch_timing.argtypes = [vp, C.POINTER(KrTiming)]
     lib.kr_llh_batch.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp, vp]
     lib.kr_place_tree_create.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
@@ -480,6 +481,24 @@ class Stream:
             self.close()
         except Exception:
             pass
+
+
+def colour_classes(pse, node_kind):
+    """Host pass of kr_index_upload over a colour table (no device): (cls[nsubsets], pse_dev[nsubsets, 2], lists)."""
+    lib = load()
+    pse = np.ascontiguousarray(pse, dtype=np.uint32).reshape(-1, 2)
+    node_kind = np.ascontiguousarray(node_kind, dtype=np.uint8)
+    n = len(pse)
+    cls = np.zeros(n, np.uint32)
+    out = np.zeros((n, 2), np.uint32)
+    nl = C.c_uint64(0)
+    rc = lib.kr_debug_colour_classes(pse.ctypes.data, n, node_kind.ctypes.data, len(node_kind) - 1, cls.ctypes.data, out.ctypes.data, None,
+                                     C.byref(nl))
+    lists = np.zeros(max(1, nl.value), np.uint32)
+    if rc != 0:  # the first call sized the list buffer
+        check(lib.kr_debug_colour_classes(pse.ctypes.data, n, node_kind.ctypes.data, len(node_kind) - 1, cls.ctypes.data, out.ctypes.data,
+                                          lists.ctypes.data, C.byref(nl)))
+    return cls, out, lists[: nl.value]
 
 
 def read_fastx(path, min_bases=76800, stats=None):

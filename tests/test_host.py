@@ -461,3 +461,93 @@ def test_cli_help_and_usage_errors():
     r = subprocess.run([exe, "dist", "-i", os.path.join(GOLDEN, "toy_index"), "-q", os.path.join(GOLDEN, "toy_reads.fq"), "--dist-max", "0.5"],
                        capture_output=True, text=True)
     assert r.returncode == 1 and "--dist-max" in r.stderr
+
+
+def _random_colour_table(rng, nleaves, nextra):
+    """A random binary tree in post-order numbering (se 1..N, leaves and internal nodes, a few of them null) followed by
+    `nextra` colours that are unions of two earlier ids (the way the index builder makes them, src/record.cpp), some of
+    them naming ids the table does not define."""
+    kind, pse, stack = [0], [(0, 0)], []
+    made = 0
+    while made < nleaves or len(stack) > 1:
+        if made < nleaves and (len(stack) < 2 or rng.random() < 0.5):
+            kind.append(1 if rng.random() > 0.03 else 0)  # a null leaf now and then
+            pse.append((0, len(kind) - 1))  # (leaf se -> (0, se), SURVEY 8b)
+            stack.append(len(kind) - 1)
+            made += 1
+        else:
+            b, a = stack.pop(), stack.pop()
+            kind.append(2 if rng.random() > 0.02 else 0)  # a null internal node now and then
+            pse.append((a, b))
+            stack.append(len(kind) - 1)
+    nnodes = len(kind) - 1
+    for _ in range(nextra):
+        n = len(pse)
+        a = int(rng.integers(0, n + 3)) if rng.random() < 0.05 else int(rng.integers(1, n))  # sometimes undefined ids
+        b = int(rng.integers(1, n))
+        if rng.random() < 0.5 and n > nnodes + 2:  # chains: a colour that grew by one part at a time
+            a = n - 1
+        pse.append((a, b))
+    return np.array(kind, np.uint8), np.array(pse, np.uint32), nnodes
+
+
+def test_flat_colours_list_exactly_the_leaves_the_walk_reaches(capi):
+    """kr_index_upload's host pass (colour_classes): a colour tagged flat must name -- as a run of ranks or as a list --
+    exactly the set of leaves that the breadth-first walk of src/query.cpp:369-387 reaches from it; leaves carry their
+    rank; null nodes and undefined ids are dropped; the parts of a walked colour carry the tags of those colours."""
+    import sys
+    rng = np.random.default_rng(20261003)
+    for nleaves, nextra in ((2, 3), (9, 40), (60, 400), (300, 3000)):
+        kind, pse, nnodes = _random_colour_table(rng, nleaves, nextra)
+        n = len(pse)
+        rank_of = {}
+        for se in range(1, nnodes + 1):
+            if kind[se] == 1:
+                rank_of[se] = len(rank_of)
+        memo = {}
+        sys.setrecursionlimit(100000)
+
+        def walk(se):  # the set of leaf ranks the reference's expansion updates
+            if se == 0 or se >= n:
+                return frozenset()
+            if se in memo:
+                return memo[se]
+            if se <= nnodes and kind[se] == 0:
+                r = frozenset()
+            elif se <= nnodes and kind[se] == 1:
+                r = frozenset([rank_of[se]])
+            else:
+                r = walk(int(pse[se][0])) | walk(int(pse[se][1]))
+            memo[se] = r
+            return r
+
+        cls, dev, lists = capi.colour_classes(pse, kind)
+        nflat = nrun = nlist = 0
+        for se in range(1, n):
+            c, low = int(cls[se]) >> 30, int(cls[se]) & 0x3FFFFFFF
+            if se <= nnodes and kind[se] == 0:
+                assert cls[se] == 0
+            elif se <= nnodes and kind[se] == 1:
+                assert c == 1 and low == rank_of[se]
+            else:
+                assert c in (2, 3) and low == se  # the id survives (the hits tap reports it)
+                if c == 3:
+                    base, cnt = int(dev[se][0]), int(dev[se][1])
+                    ranks = lists[(base & 0x7FFFFFFF): (base & 0x7FFFFFFF) + cnt].tolist() if base >> 31 else list(range(base, base + cnt))
+                    assert ranks == sorted(walk(se)), se
+                    nflat += 1
+                    nlist += base >> 31
+                    nrun += 1 - (base >> 31)
+                else:
+                    for part, tagged in zip(pse[se].tolist(), dev[se].tolist()):
+                        assert tagged == (int(cls[part]) if part < n else 0)
+                    # walked only when it has to be: a part that is walked itself (or defined later), or more than 64
+                    # leaves counting a leaf reached through both parts twice
+                    def size(part):
+                        if part == 0 or part >= n or (int(cls[part]) >> 30) == 0:
+                            return 0
+                        return 1 if (int(cls[part]) >> 30) == 1 else (int(dev[part][1]) if (int(cls[part]) >> 30) == 3 else 1 << 30)
+                    a_, b_ = pse[se].tolist()
+                    assert a_ >= se or b_ >= se or size(a_) + size(b_) > 64, se
+        if nleaves >= 60:
+            assert nrun > 10 and nlist > 10 and nflat > 0.3 * nextra
