@@ -178,7 +178,9 @@ KR_API void kr_stream_destroy(kr_stream*);
                            /* buffers, which must stay valid until the batch has been waited for         */
 #define KR_ROWS_ONLY 16u   /* kr_batch_collect brings back only what the `dist` report needs         */
                            /* (read_off/cnt/na, rec_key/sel/d); rec_v, rec_chisq, rec_hist and        */
-                           /* read_onmers of the host view are then NULL / undefined                  */
+                           /* read_onmers of the host view are then NULL / undefined, and the kernels */
+                           /* do not write rec_v at all (NULL in a device view too) unless the batch  */
+                           /* filters (--filter) or taps                                              */
 
 /* Queue one batch: `bases` = concatenated ASCII sequences exactly as the FASTX
  * reader delivers them (QSeq::read_next_batch, src/rqseq.cpp:180-197),
