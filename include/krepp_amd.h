@@ -363,6 +363,10 @@ KR_API int kr_place_batch(const kr_host_index*, const kr_index*, const kr_place_
 KR_API int kr_place_stream(const kr_host_index*, const kr_index*, const kr_place_tree*, kr_stream* s, uint32_t nreads,
                            const uint64_t* offsets, const char* const* names, const kr_params* p, int tabular,
                            int* has_previous, char** text, uint64_t* len, kr_placement** placements, uint64_t* nplacements);
+/* How many kr_place_stream batches of this process ran their back end on the device, and how many were sent whole to the
+ * host back end (kr_place_batch: a placement tree that is not numbered in post-order, KR_PLACE_HOST set, or a batch the
+ * device could not hold).  Either pointer may be NULL. */
+KR_API void kr_place_counters(uint64_t* device_batches, uint64_t* host_batches);
 /* `tabular`: 0 jplace, 1 --tabular, 2 --summarize (no per-read text; feed the placements to
  * kr_place_summary_add).  place --summarize (src/krepp.cpp:466-471,493-497): `wcount` has
  * kr_place_tree_nnodes + 1 doubles, zeroed by the caller before the first batch and indexed by edge + 1. */

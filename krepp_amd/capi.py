@@ -89,7 +89,7 @@ EXPORTS = [
     "kr_batch_collect", "kr_batch_collect_device", "kr_batch_hits", "kr_batch_readtaps",
     "kr_debug_front_end", "kr_debug_brent", "kr_debug_colour_classes", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
     "kr_place_tree_create", "kr_place_tree_create_lineage", "kr_place_tree_nnodes", "kr_place_summary_add",
-    "kr_place_summary_text", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_stream", "kr_place_frame",
+    "kr_place_summary_text", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_stream", "kr_place_frame", "kr_place_counters",
     "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_format_dist", "kr_free", "kr_host_alloc", "kr_host_free",
     "kr_build_index", "kr_minimizers_cpu", "kr_minimizers_device", "kr_minimizers_free", "kr_last_error", "kr_version",
 ]
@@ -166,6 +166,8 @@ def load():
     lib.kr_place_stream.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, C.POINTER(C.c_char_p), C.POINTER(KrParams), C.c_int,
                                     C.POINTER(C.c_int), C.POINTER(vp), u64p, C.POINTER(vp), u64p]
     lib.kr_place_frame.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_uint64, C.POINTER(vp), u64p]
+    lib.kr_place_counters.argtypes = [u64p, u64p]
+    lib.kr_place_counters.restype = None
     lib.kr_fastx_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.kr_fastx_next.argtypes = [vp, C.c_uint64, C.POINTER(KrFastxBatch)]
     lib.kr_fastx_close.argtypes = [vp]
@@ -528,6 +530,13 @@ def read_fastx(path, min_bases=76800, stats=None):
     offsets = np.zeros(len(lens) + 1, np.uint64)
     offsets[1:] = np.cumsum(np.asarray(lens, dtype=np.uint64))
     return names, bases, offsets
+
+
+def place_counters():
+    """(batches whose `place` back end ran on the device, batches sent whole to the host back end) of this process."""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    load().kr_place_counters(C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
 
 
 def build_index(input_tsv, out_dir, nwk=None, k=29, w=35, h=13, m=4, r=1, frac=True, num_threads=1, seed=0, ppos=None,

@@ -14,6 +14,7 @@
 #include "kr_common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -115,6 +116,9 @@ char* dup_text(const std::string& s, uint64_t* len)
 }
 
 } // namespace
+
+// kr_place_stream batches of this process by back end (kr_place_counters): on the device, or sent whole to the host path
+static std::atomic<uint64_t> g_place_device_batches{0}, g_place_host_batches{0};
 
 extern "C" {
 
@@ -808,6 +812,7 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
   if (!hx || !dix || !pt || !s || !offsets || !p || !has_previous || !text || !len || !nreads)
     return kr::fail(KR_ERR_ARG, "kr_place_stream: null argument");
   auto host_path = [&]() -> int {
+    g_place_host_batches.fetch_add(1, std::memory_order_relaxed);
     kr_result_view rv;
     int rc = kr_batch_collect(s, &rv);
     if (rc) return rc;
@@ -838,6 +843,7 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
   if (res.nreads != nreads) return kr::fail(KR_ERR_ARG, "kr_place_stream: nreads does not match the submitted batch");
   lap("A-C: aggregation, Brent, chi-square on the device + copy back");
   if (res.overflow) return host_path();
+  g_place_device_batches.fetch_add(1, std::memory_order_relaxed);
   // each read's candidates in ascending node number (the order the host path forms them in), straight from the
   // arrays the device wrote
   struct DeviceSource {
@@ -855,6 +861,12 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
     }
   } src{res};
   return emit_placements(pt, nreads, src, names, p, tabular, has_previous, text, len, placements, nplacements, lap);
+}
+
+void kr_place_counters(uint64_t* device_batches, uint64_t* host_batches)
+{
+  if (device_batches) *device_batches = g_place_device_batches.load(std::memory_order_relaxed);
+  if (host_batches) *host_batches = g_place_host_batches.load(std::memory_order_relaxed);
 }
 
 uint32_t kr_place_tree_nnodes(const kr_place_tree* pt) { return pt ? pt->t.nnodes() : 0; }

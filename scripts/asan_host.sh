@@ -10,6 +10,6 @@ done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/asan/libkrepp_amd.so build/kr_device.o build/kr_minimizer.o /tmp/asan/kr_host.o /tmp/asan/kr_build.o /tmp/asan/kr_place.o -lz -lgomp -ldl
 cd ../..
 cp krepp_amd/lib/libkrepp_amd.so /tmp/asan/orig.so
+trap 'cp /tmp/asan/orig.so krepp_amd/lib/libkrepp_amd.so' EXIT # whatever happens below, the product library comes back
 cp /tmp/asan/libkrepp_amd.so krepp_amd/lib/libkrepp_amd.so
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python -m pytest tests -m "not gpu" -x -q -p no:cacheprovider || true
-cp /tmp/asan/orig.so krepp_amd/lib/libkrepp_amd.so

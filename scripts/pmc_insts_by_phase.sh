@@ -2,6 +2,7 @@
 # Wave-instruction counts of the lean accumulate kernel by phase: KR_DEBUG_SKIP ablations (2: no items, 16: no events kept,
 # 64: no keys, 128: no plane pass, 256: no record output) under rocprofv3 --pmc SQ_INSTS_*; differences between rows = phases.
 export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=8 # before the profiler's preload initialises the runtime
 for v in ${SKIPS:-0 256 128 64 16 2}; do
   rm -rf gpurun_out/pmci_$v; mkdir -p gpurun_out/pmci_$v
   KR_DEBUG_SKIP=$v rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d gpurun_out/pmci_$v -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-inclusive --check-reads 1000 --reads-per-step 1000000 --read-procs 1 --distinct-batches 1 > gpurun_out/pmci_$v/log.txt 2>&1

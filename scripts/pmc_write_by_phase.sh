@@ -1,4 +1,5 @@
 export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=8 # before the profiler's preload initialises the runtime
 for v in ${SKIPS:-0 256 64 16 2}; do
   rm -rf gpurun_out/pmcw_$v; mkdir -p gpurun_out/pmcw_$v
   KR_DEBUG_SKIP=$v rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmcw_$v -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-inclusive --check-reads 1000 --reads-per-step 1000000 --read-procs 1 --distinct-batches 1 > gpurun_out/pmcw_$v/log.txt 2>&1

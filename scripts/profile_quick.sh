@@ -2,6 +2,7 @@
 # kernel trace + SQ counters only.  usage: scripts/profile_quick.sh <tag> [bench args...]
 TAG=$1; shift
 export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=8 # before the profiler's preload initialises the runtime
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-host-inclusive --read-procs 1 --distinct-batches 1 $@"

@@ -30,15 +30,16 @@ slotted = "--packed" not in sys.argv  # scripts/profile.sh runs the default (slo
 small = 0.0 if slotted else min(req, n * per["probes"])  # isolated descriptor gathers: one request, 64 B each
 lines = req - small
 import os
-commit = os.environ.get("KR_COMMIT")  # the GPU box has no .git: the caller passes the commit the snapshot was taken at
-if not commit:
-    try:
-        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
-    except Exception:
-        commit = None
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from krepp_amd import srcinfo
+# the GPU box has no .git: build() recorded, where it had one, the commit that last touched the scan kernel's sources and a
+# digest of them; the digest is recomputed here from the files that were profiled
+bi = srcinfo.build_info()
+commit = bi.get("scan_commit")
 out = {
     "kernel": "kr_scan_kernel", "workload": b["config"]["workload"], "table": "slotted" if slotted else "packed",
-    "profile": tag, "commit": commit, "scan_ms": b["kernel_ms"]["scan"],
+    "profile": tag, "commit": commit, "head_at_build": bi.get("head"), "scan_src_sha": bi["scan_src_sha"],
+    "scan_sources": list(srcinfo.SCAN_SOURCES), "scan_ms": b["kernel_ms"]["scan"],
     "reads_per_launch": n, "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
     "read_requests": req, "isolated_gather_requests": small, "line_requests": lines,
     "hbm_bytes_lower_bound_all_64B": fetch_b + write_b,

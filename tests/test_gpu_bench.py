@@ -45,3 +45,16 @@ def test_bench_default_line_small():
     assert out["check"]["rows_equal"]
     hi = out["value_host_inclusive"]
     assert hi["value"] > 0 and hi["streams"] == 3
+
+
+def test_bench_one_rank_rccl_replicates_the_index():
+    """`--force-replicate`: the N-rank replication path (kr_index_export -> DevPtr tensors over the library's own device
+    buffers -> dist.broadcast per buffer) on a ONE-rank `nccl` (= RCCL) process group, on the GPU: torch, RCCL and raw
+    device pointers meet on hardware here, before the driver's 8-GPU run (src/krepp.cpp:92-106 is the load loop it
+    replaces).  The index that went through it still answers like the oracle."""
+    out = run_bench("--force-replicate", "--backend", "nccl", "--workload", "toy25", "--reads-per-step", "100000", "--steps", "2",
+                    "--warmup", "1", "--no-cpu-baseline", "--no-host-inclusive", "--check-reads", "3000", "--distinct-batches", "1")
+    bc = out["index_broadcast"]
+    assert bc["backend"] == "nccl" and bc["world"] == 1 and bc["bytes"] == out["config"]["index_device_bytes"] > 1e6
+    assert bc["seconds"] > 0 and bc["GB_per_s"] > 0
+    assert out["n_gpus"] == 1 and out["check"]["rows_equal"] and out["check"]["max_rel_dist_err"] < 1e-6

@@ -540,6 +540,13 @@ def test_lanes_do_not_change_results(capi, toy, toy_genomes, synth, monkeypatch)
         std.submit_device(tb.data_ptr(), to.data_ptr(), len(offs) - 1)
         rv = std.collect_device()
         assert std.timing().lanes == int(lanes)
+        # without KR_TAP_ACCS the planes of most records are never written: the view must not expose them (include/krepp_amd.h)
+        assert not rv.rec_hist and rv.rec_hist_stride == 0 and rv.rec_d and rv.rec_key
+        std.submit_device(tb.data_ptr(), to.data_ptr(), len(offs) - 1, capi.KR_TAP_ACCS)
+        rva = std.collect_device()
+        assert rva.rec_hist and rva.rec_hist_stride > 0 and rva.rec_v
+        std.submit_device(tb.data_ptr(), to.data_ptr(), len(offs) - 1)
+        rv = std.collect_device()
 
         class DevPtr:
             def __init__(self, ptr, nbytes):

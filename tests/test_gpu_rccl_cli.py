@@ -1,0 +1,39 @@
+"""kr_index_broadcast in a process WITHOUT torch: a plain-C program over include/krepp_amd.h replicates an
+uploaded index onto its own device through RCCL -- the library dlopen()s librccl.so.1 by itself, nobody has loaded torch's
+private copy for it -- and answers queries from the replica; and `krepp dist --gpus 1` as the stand-alone CLI.  The load loop
+this replaces for the GPUs after the first: src/krepp.cpp:92-106."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_plain_c_process_replicates_through_rccl_and_queries_the_replica(po, toy_index_dir, toy_reads, tmp_path):
+    exe = str(tmp_path / "replica_driver")
+    lib = os.path.join(ROOT, "krepp_amd", "lib")
+    subprocess.run(["gcc", "-O1", "-std=c11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_drivers", "replica_driver.c"),
+                    "-o", exe, "-L", lib, "-lkrepp_amd", f"-Wl,-rpath,{lib}"], check=True)
+    fq = os.path.join(GOLDEN, "toy_reads.fq")
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "PYTHONPATH", "KR_RCCL_LIB")}
+    r = subprocess.run([exe, toy_index_dir, fq], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rccl = [l for l in r.stderr.splitlines() if l.startswith("rccl: ")]
+    assert len(rccl) == 1 and "librccl" in rccl[0] and "torch" not in rccl[0], r.stderr  # the system RCCL, not torch's private copy
+    names, bases, offs = toy_reads
+    want = po.Index(toy_index_dir).dist(bases, offs, names, po.params(collect=4))["text"]
+    assert r.stdout == want
+
+
+def test_cli_dist_gpus_1_without_python(po, toy_index_dir, toy_reads):
+    exe = os.path.join(ROOT, "krepp_amd", "lib", "krepp")
+    fq = os.path.join(GOLDEN, "toy_reads.fq")
+    r = subprocess.run([exe, "dist", "-i", toy_index_dir, "-q", fq, "--gpus", "1", "--device", "0"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names, bases, offs = toy_reads
+    want = po.Index(toy_index_dir).dist(bases, offs, names, po.params(collect=4))["text"]
+    body = r.stdout.split("\n", 2)[2]  # two header lines (src/krepp.cpp:311-319)
+    assert body == want

@@ -114,9 +114,9 @@ def test_syn1000_10gb_index_vs_oracle_and_full_batch_properties(capi, po, synth,
 
 
 def test_ten_thousand_genome_index_vs_oracle(capi, po, synth, tmp_path):
-    """The index shape of BASELINE.json configs[3] on one GPU: 10,000 genomes on a Yule tree (default parameters, 2^25 rows;
-    the table inflated to 2 GB to keep the test short -- the 8-GPU run replicates this index per GPU and shards the reads,
-    which changes nothing per GPU).  4,000 reads against the oracle: hits, histograms, rows; then 200,000 reads through the
+    """The per-GPU part of BASELINE.json configs[3] at full size: 10,000 genomes on a Yule tree (default parameters, 2^25
+    rows), the table inflated to the config's 10 GB resident in HBM -- the index of `bench.py --workload syn10000`, same
+    seeds; the 8-GPU run replicates this index per GPU and shards the reads, which changes nothing per GPU.  4,000 reads against the oracle: hits, histograms, rows; then 200,000 reads through the
     reverse-complement property.  20,000 key slots per wave: the accumulate kernel runs with fewer resident waves and its
     global-scratch paths are live."""
     import torch
@@ -129,10 +129,11 @@ def test_ten_thousand_genome_index_vs_oracle(capi, po, synth, tmp_path):
     idx = str(tmp_path / "idx")
     capi.build_index(tsv, idx, nwk=str(tmp_path / "y.nwk"), k=29, w=35, h=13, m=4, r=1, frac=True, num_threads=min(32, os.cpu_count() or 1))
     hx = capi.HostIndex(idx)
-    dx, (inc, cmer) = synth.inflate_and_upload(torch, capi, hx, torch.device("cuda", 0), 0, 2.0, seed=20260103)
+    dx, (inc, cmer) = synth.inflate_and_upload(torch, capi, hx, torch.device("cuda", 0), 0, INDEX_GB)
     try:
         ox = po.Index(idx)
         assert ox.info.nleaves == n_genomes
+        assert len(inc) == 1 << 25 and cmer.size // 2 * 8 >= 0.99 * INDEX_GB * 1e9 and dx.device_bytes > 18e9  # 10 GB table + slots
         ox.replace_table(0, inc, cmer)
         del inc, cmer
         n = 4000
