@@ -37,6 +37,7 @@
 // One translation unit in several files, included below in this order (device code first):
 //   kr_dev_common.inc      constants, device structs and helpers, accumulator tables, colour expansion
 //   kr_dev_scan.inc        kernel 1: probe list, bucket scan, hit items
+//   kr_dev_scan_pipe.inc   kernel 1 for slotted tables as a software pipeline across probe groups
 //   kr_dev_accumulate.inc  kernel 2: event epilogue, plane tables, records
 //   kr_dev_likelihood.inc  likelihood, Brent, de-duplication, selection kernels
 //   kr_dev_place.inc       back end of `place`: ancestor accumulation, candidates, their likelihoods (kr_place_kernel)
@@ -49,6 +50,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <unistd.h>
 #include <type_traits>
 
 #include "kr_common.h"
@@ -71,6 +73,7 @@ namespace {
 
 #include "kr_dev_common.inc"
 #include "kr_dev_scan.inc"
+#include "kr_dev_scan_pipe.inc"
 #include "kr_dev_accumulate.inc"
 #include "kr_dev_likelihood.inc"
 #include "kr_dev_place.inc"

@@ -15,7 +15,7 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # everything kr_scan_kernel_t is compiled from (front end, probe list, slot scan, item stage) and nothing else
-SCAN_SOURCES = ("krepp_amd/csrc/kr_dev_scan.inc", "krepp_amd/csrc/kr_dev_common.inc", "krepp_amd/csrc/kr_devutil.h")
+SCAN_SOURCES = ("krepp_amd/csrc/kr_dev_scan.inc", "krepp_amd/csrc/kr_dev_scan_pipe.inc", "krepp_amd/csrc/kr_dev_common.inc", "krepp_amd/csrc/kr_devutil.h")
 BUILD_INFO = os.path.join(ROOT, "krepp_amd", "lib", "build_info.json")
 
 

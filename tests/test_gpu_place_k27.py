@@ -76,6 +76,7 @@ def test_place_k27_h11_one_million_reads_device_equals_host_no_fallback(capi, sy
     text_d, pl_d = placer.place(bases, offs, names, host=False, c_names=c_names)
     dev1, host1 = capi.place_counters()
     assert (dev1 - dev0, host1 - host0) == (1, 0), "the 1 M-read batch did not run its back end on the device"
+    placer.prev = C.c_int(0)  # (a second batch of one run would start with the jplace separator)
     text_h, pl_h = placer.place(bases, offs, names, host=True, c_names=c_names)
     assert len(pl_d) > N_FULL // 2 and len(np.unique(pl_d["read"])) > N_FULL // 2
     assert pl_d.tobytes() == pl_h.tobytes(), "device and host back ends differ in a placement"
