@@ -359,14 +359,17 @@ KR_API int kr_place_batch(const kr_host_index*, const kr_index*, const kr_place_
  * report_placement up to the candidate list -- ancestor accumulation (Minfo::add, src/query.hpp:139-152;
  * src/query.cpp:248-265), candidate listing (:268-272), Brent on the internal candidates (:273-275) and the
  * chi-square of every candidate (:276) -- runs on the device, on the records where they lie; the host receives
- * the candidates and does the last phase (filter, LWR, Jukes-Cantor, text).  Output identical to kr_place_batch. */
+ * the candidates and does the last phase (filter, LWR, Jukes-Cantor, text).  Output identical to kr_place_batch.
+ * Reads of any weight stay on the device (see kr_place_counters). */
 KR_API int kr_place_stream(const kr_host_index*, const kr_index*, const kr_place_tree*, kr_stream* s, uint32_t nreads,
                            const uint64_t* offsets, const char* const* names, const kr_params* p, int tabular,
                            int* has_previous, char** text, uint64_t* len, kr_placement** placements, uint64_t* nplacements);
 /* How many kr_place_stream batches of this process ran their back end on the device, and how many were sent whole to the
- * host back end (kr_place_batch: a placement tree that is not numbered in post-order, KR_PLACE_HOST set, or a batch the
- * device could not hold).  Either pointer may be NULL. */
-KR_API void kr_place_counters(uint64_t* device_batches, uint64_t* host_batches);
+ * host back end (kr_place_batch: a placement tree that is not numbered in post-order, KR_PLACE_HOST set, or a batch that ran
+ * out of candidate slots); heavy_reads: reads with more leaves / distinct ancestors than kr_place_kernel's LDS arrays hold
+ * (256 / 1024), which its second launch does with the arrays in global scratch (counted in list chunks of 8: an upper
+ * bound, 0 when there was none).  Any pointer may be NULL. */
+KR_API void kr_place_counters(uint64_t* device_batches, uint64_t* host_batches, uint64_t* heavy_reads);
 /* `tabular`: 0 jplace, 1 --tabular, 2 --summarize (no per-read text; feed the placements to
  * kr_place_summary_add).  place --summarize (src/krepp.cpp:466-471,493-497): `wcount` has
  * kr_place_tree_nnodes + 1 doubles, zeroed by the caller before the first batch and indexed by edge + 1. */

@@ -166,7 +166,7 @@ def load():
     lib.kr_place_stream.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, C.POINTER(C.c_char_p), C.POINTER(KrParams), C.c_int,
                                     C.POINTER(C.c_int), C.POINTER(vp), u64p, C.POINTER(vp), u64p]
     lib.kr_place_frame.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_uint64, C.POINTER(vp), u64p]
-    lib.kr_place_counters.argtypes = [u64p, u64p]
+    lib.kr_place_counters.argtypes = [u64p, u64p, u64p]
     lib.kr_place_counters.restype = None
     lib.kr_fastx_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.kr_fastx_next.argtypes = [vp, C.c_uint64, C.POINTER(KrFastxBatch)]
@@ -535,8 +535,15 @@ def read_fastx(path, min_bases=76800, stats=None):
 def place_counters():
     """(batches whose `place` back end ran on the device, batches sent whole to the host back end) of this process."""
     a, b = C.c_uint64(0), C.c_uint64(0)
-    load().kr_place_counters(C.byref(a), C.byref(b))
+    load().kr_place_counters(C.byref(a), C.byref(b), None)
     return int(a.value), int(b.value)
+
+
+def place_heavy_reads():
+    """Reads (upper bound, in chunks of 8) that kr_place_kernel's second launch did with its arrays in global scratch."""
+    c = C.c_uint64(0)
+    load().kr_place_counters(None, None, C.byref(c))
+    return int(c.value)
 
 
 def build_index(input_tsv, out_dir, nwk=None, k=29, w=35, h=13, m=4, r=1, frac=True, num_threads=1, seed=0, ppos=None,

@@ -132,7 +132,8 @@ struct PlaceDeviceResult { // page-locked host arrays owned by the stream, valid
   const uint32_t* rd_info = nullptr; // [nreads] bit 31: reported, bit 30: single placement, low 30 bits: candidates
   const uint32_t* c_se = nullptr;    // per candidate slot: placement-tree node, d_llh, v_llh, chi-square
   const double *c_d = nullptr, *c_v = nullptr, *c_chisq = nullptr;
-  bool overflow = false;             // a read exceeded the kernel's per-read limits: take the host path for the batch
+  bool overflow = false;             // the device ran out of candidate slots: take the host path for the batch
+  uint32_t heavy_reads = 0;          // reads beyond the LDS arrays of kr_place_kernel, done by its second launch (upper bound)
 };
 } // namespace kr
 struct kr_stream;

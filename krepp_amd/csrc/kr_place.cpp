@@ -118,7 +118,7 @@ char* dup_text(const std::string& s, uint64_t* len)
 } // namespace
 
 // kr_place_stream batches of this process by back end (kr_place_counters): on the device, or sent whole to the host path
-static std::atomic<uint64_t> g_place_device_batches{0}, g_place_host_batches{0};
+static std::atomic<uint64_t> g_place_device_batches{0}, g_place_host_batches{0}, g_place_heavy_reads{0};
 
 extern "C" {
 
@@ -802,8 +802,9 @@ int kr_place_batch(const kr_host_index* hx, const kr_index* dix, const kr_place_
 // aggregation, the Brent minimisations of the internal candidates and the chi-squares run on the device
 // (kr_place_kernel) on the records where they lie; what comes back is the candidates (node, d, v, chi-square), and the
 // host does the last phase only (filter, exp / LWR, Jukes-Cantor, text).  Bit-identical to kr_place_batch.  Reads
-// beyond the kernel's per-read limits (256 leaves / 1024 ancestors), or a placement tree whose numbering is not
-// post-order, send the whole batch through kr_place_batch.
+// beyond the kernel's LDS arrays (256 leaves / 1024 ancestors) are done by its second launch with the arrays in global
+// scratch; only a placement tree whose numbering is not post-order (or a batch that runs out of candidate slots) sends
+// the whole batch through kr_place_batch.
 int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place_tree* pt, kr_stream* s, uint32_t nreads,
                     const uint64_t* offsets, const char* const* names, const kr_params* p, int tabular, int* has_previous, char** text,
                     uint64_t* len, kr_placement** placements, uint64_t* nplacements)
@@ -844,6 +845,7 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
   lap("A-C: aggregation, Brent, chi-square on the device + copy back");
   if (res.overflow) return host_path();
   g_place_device_batches.fetch_add(1, std::memory_order_relaxed);
+  g_place_heavy_reads.fetch_add(res.heavy_reads, std::memory_order_relaxed);
   // each read's candidates in ascending node number (the order the host path forms them in), straight from the
   // arrays the device wrote
   struct DeviceSource {
@@ -863,10 +865,11 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
   return emit_placements(pt, nreads, src, names, p, tabular, has_previous, text, len, placements, nplacements, lap);
 }
 
-void kr_place_counters(uint64_t* device_batches, uint64_t* host_batches)
+void kr_place_counters(uint64_t* device_batches, uint64_t* host_batches, uint64_t* heavy_reads)
 {
   if (device_batches) *device_batches = g_place_device_batches.load(std::memory_order_relaxed);
   if (host_batches) *host_batches = g_place_host_batches.load(std::memory_order_relaxed);
+  if (heavy_reads) *heavy_reads = g_place_heavy_reads.load(std::memory_order_relaxed);
 }
 
 uint32_t kr_place_tree_nnodes(const kr_place_tree* pt) { return pt ? pt->t.nnodes() : 0; }

@@ -172,3 +172,34 @@ def test_ten_thousand_genome_index_vs_oracle(capi, po, synth, tmp_path):
         dx.close()
         hx.close()
         torch.cuda.empty_cache()
+
+
+def test_place_on_the_1000_genome_tree_never_leaves_the_device(capi, synth, syn):
+    """`krepp place` on the 1000-genome index with its own Yule tree as backbone (the index as built, 8.3 M entries): reads
+    there reach dozens of leaves on average and hundreds in the tail -- more than kr_place_kernel's LDS arrays hold (256
+    leaves / 1024 distinct ancestors); those reads take the kernel's second launch (arrays in global scratch) and no batch
+    falls back to the host back end.  200,000 reads: text and placements of the device back end equal the host back end's
+    (kr_place_batch) bit for bit (src/query.cpp:218-333)."""
+    import ctypes as C
+
+    idx, genomes = syn
+    n = 200_000
+    bases, offs = make_reads(synth, genomes, n, seed=77)
+    names = [f"q{i}" for i in range(n)]
+    c_names = (C.c_char_p * n)(*[x.encode() for x in names])
+    hx = capi.HostIndex(idx)
+    placer = capi.Placer(hx, None, 0, tabular=True, max_reads=n, max_bases=len(bases))
+    try:
+        d0, h0 = capi.place_counters()
+        hv0 = capi.place_heavy_reads()
+        text_d, pl_d = placer.place(bases, offs, names, host=False, c_names=c_names)
+        d1, h1 = capi.place_counters()
+        assert (d1 - d0, h1 - h0) == (1, 0), "the batch fell back to the host back end"
+        heavy = capi.place_heavy_reads() - hv0
+        text_h, pl_h = placer.place(bases, offs, names, host=True, c_names=c_names)
+        assert len(pl_d) > n // 2
+        assert pl_d.tobytes() == pl_h.tobytes() and text_d == text_h
+        print(f"heavy reads (upper bound): {heavy} of {n}")
+    finally:
+        placer.close()
+        hx.close()

@@ -354,3 +354,36 @@ def test_cli_dist_on_a_file_large_enough_for_the_parallel_reader(po, toy_index_d
                         env=dict(os.environ, KR_DEBUG_CLI_RECORDS="20000"))
     assert r2.returncode == 0, r2.stderr
     assert r2.stdout.splitlines()[2:] == got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("limits", ["3,8", "1,1", "6,1024"])
+def test_heavy_reads_stay_on_the_device(capi, po, toy_index_dir, toy_reads, toy_genomes, synth, monkeypatch, limits):
+    """Reads with more leaves / distinct ancestors than kr_place_kernel's LDS arrays hold (256 / 1024; lowered here so
+    that the 25-leaf tree has such reads) are done by the kernel's second launch with its arrays in global scratch:
+    no batch goes to the host back end, and text, placements and summary equal the host back end's bit for bit and
+    the oracle's (src/query.cpp:248-281, Minfo::add src/query.hpp:139-152)."""
+    names, bases, offs = toy_reads
+    b2, o2, n2 = synth.sample_reads(toy_genomes, 5000, seed=29)
+    hx = capi.HostIndex(toy_index_dir)
+    ox = po.Index(toy_index_dir)
+    ox.set_placement_tree(None)
+    monkeypatch.setenv("KR_DEBUG_PLACE_LDS", limits)
+    for rb, ro, rn in ((bases, offs, names), (b2, o2, n2)):
+        for tabular in (0, 1, 2):
+            out = []
+            for host in (False, True):
+                pl = capi.Placer(hx, None, 0, tabular=tabular, max_reads=len(rn), max_bases=len(rb))
+                d0, h0 = capi.place_counters()
+                hv0 = capi.place_heavy_reads()
+                text, p = pl.place(rb, ro, rn, host=host)
+                d1, h1 = capi.place_counters()
+                if not host:
+                    assert (d1 - d0, h1 - h0) == (1, 0), "the batch left the device"
+                    assert capi.place_heavy_reads() - hv0 > len(rn) // 10, "no read took the second launch"
+                out.append((text, p.tobytes(), pl.summary() if tabular == 2 else ""))
+                pl.close()
+            assert out[0] == out[1], (limits, tabular)
+            if tabular != 2:
+                want = ox.place(rb, ro, rn, po.params(no_filter=0), tabular=bool(tabular))
+                assert out[0][0] == want["text"]
