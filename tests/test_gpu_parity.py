@@ -228,7 +228,7 @@ def test_long_reads_and_ragged_batches(capi, po, toy, toy_genomes):
         os.environ.pop("KR_LANE_MIN_READS"), os.environ.pop("KR_LANES")
 
 
-@pytest.mark.parametrize("slot_log2w,dbg", [("0", "8192"), ("5", "8192"), ("6", "8192"), ("6", "0")])
+@pytest.mark.parametrize("slot_log2w,dbg", [("0", "8192"), ("5", "8192"), ("6", "8192"), ("6", "0"), ("8", "0")])
 def test_overflow_path_many_leaves(capi, po, synth, tmp_path, monkeypatch, slot_log2w, dbg):
     """150-bp reads with k = 21 have 130 k-mer positions = two segments.  With debug bit 8192 they take the
     plane tables, and reads that reach more (strand, leaf) pairs than the LDS table holds go on to the

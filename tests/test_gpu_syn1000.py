@@ -2,8 +2,8 @@
 parameters -k 29 -w 35 -h 13, m4r1-frac: 2^25 rows) whose table is inflated to 10 GB resident in HBM — the
 exact index bench.py measures (krepp_amd.synth.inflate_and_upload, same seeds).
 
-Per table layout (the default slotted copy of the bucket heads, W = 64 words; and KR_SLOT_LOG2W=0, the packed
-table only): 20,000 reads against the oracle holding the same table (Index.replace_table) — table hits
+Per table layout (the slotted copy of the bucket heads with W = 64 words; with W = 48 words = 192-byte slots, where 7 % of
+the buckets continue in the packed array; and KR_SLOT_LOG2W=0, the packed table only): 20,000 reads against the oracle holding the same table (Index.replace_table) — table hits
 (src/query.cpp:352-368, src/index.cpp:160-168) and histograms (src/query.hpp:153-176) bit-exact, DIST within the
 north star's 1e-6 relative — then a full 1,000,000-read batch through the size-independent properties
 (reverse complement, permutation, split).
@@ -39,7 +39,7 @@ def make_reads(synth, genomes, n, seed):
     return np.concatenate(chunks), np.arange(n + 1, dtype=np.uint64) * np.uint64(150)
 
 
-@pytest.mark.parametrize("slot_log2w", [None, "0"], ids=["slotted_w64", "packed"])
+@pytest.mark.parametrize("slot_log2w", [None, "8", "0"], ids=["slotted_w64", "slotted_w48", "packed"])
 def test_syn1000_10gb_index_vs_oracle_and_full_batch_properties(capi, po, synth, syn, monkeypatch, slot_log2w):
     import torch
 
@@ -52,8 +52,8 @@ def test_syn1000_10gb_index_vs_oracle_and_full_batch_properties(capi, po, synth,
     try:
         nk = cmer.size // 2
         assert len(inc) == 1 << 25 and nk * 8 >= 0.99 * INDEX_GB * 1e9
-        # slotted: 2^25 rows x 256 B of slots on top of the packed table; packed: no slots
-        assert (dx.device_bytes > 18e9) == (slot_log2w is None)
+        # slotted: 2^25 rows x 256 B (or 192 B: format 8) of slots on top of the packed table; packed: no slots
+        assert (dx.device_bytes > 18e9) == (slot_log2w is None) and (dx.device_bytes > 16e9) == (slot_log2w != "0")
         ox = po.Index(idx)
         ox.replace_table(0, inc, cmer)
         del inc, cmer
