@@ -35,9 +35,10 @@
 // makefile:7), and the likelihood follows its operation order.
 //
 // One translation unit in several files, included below in this order (device code first):
-//   kr_dev_common.inc      constants, device structs and helpers, accumulator tables, colour expansion
+//   kr_dev_common.inc      constants, device structs and helpers shared by the kernels
 //   kr_dev_scan.inc        kernel 1: probe list, bucket scan, hit items
 //   kr_dev_scan_pipe.inc   kernel 1 for slotted tables as a software pipeline across probe groups
+//   kr_dev_expand.inc      accumulator tables, leaf events, colour classes and colour expansion (kernel 2 only)
 //   kr_dev_accumulate.inc  kernel 2: event epilogue, plane tables, records
 //   kr_dev_likelihood.inc  likelihood, Brent, de-duplication, selection kernels
 //   kr_dev_place.inc       back end of `place`: ancestor accumulation, candidates, their likelihoods (kr_place_kernel)
@@ -74,6 +75,7 @@ namespace {
 #include "kr_dev_common.inc"
 #include "kr_dev_scan.inc"
 #include "kr_dev_scan_pipe.inc"
+#include "kr_dev_expand.inc"
 #include "kr_dev_accumulate.inc"
 #include "kr_dev_likelihood.inc"
 #include "kr_dev_place.inc"
@@ -91,10 +93,10 @@ namespace {
   } while (0)
 
 // dynamic LDS bytes of the probe kernel: stack + probe list + ntouched (+ table)
-uint32_t probe_lds_bytes(uint32_t np, uint32_t bm_words, bool lean = false)
+uint32_t probe_lds_bytes(uint32_t np, uint32_t bm_words, bool lean = false, uint32_t segs = 1)
 {
-  if (lean) // single-segment instantiation: short stack (bitmap aliases it) | key slots | event region
-    return (lean_stack_bytes(bm_words) + kLdsSlots * 4 + lean_ev_words(np) * 4 + 15u) & ~15u;
+  if (lean) // single-segment layout (segs = 2: its two-segment instantiation): short stack (bitmap aliases it) | key slots | event region
+    return (lean_stack_bytes(bm_words) + kLdsSlots * 4 + lean_ev_words(np, segs) * 4 + 15u) & ~15u;
   uint32_t b = kStackCap * 8;
   b += kLdsSlots * 4 + kLdsSlots * np * kPlaneWords * 4 + kLdsSlots * np * 4 + 2 * bm_words * 4 + bm_words; // two bitmaps + u16 prefix per 2 words
   if (getenv("KR_DEBUG_LDS_PAD")) b += (uint32_t)atoi(getenv("KR_DEBUG_LDS_PAD")); // occupancy experiments
