@@ -130,7 +130,8 @@ struct PlaceDeviceResult { // page-locked host arrays owned by the stream, valid
   uint32_t nreads = 0;
   const uint32_t* rd_c0 = nullptr;   // [nreads] first candidate slot of the read
   const uint32_t* rd_info = nullptr; // [nreads] bit 31: reported, bit 30: single placement, low 30 bits: candidates
-  const uint32_t* c_se = nullptr;    // per candidate slot: placement-tree node, d_llh, v_llh, chi-square
+  const uint32_t* c_se = nullptr;    // per KEPT candidate (chi-square below --chisq, not the root; a read's in emission order):
+                                     // placement-tree node, d_llh, v_llh, chi-square
   const double *c_d = nullptr, *c_v = nullptr, *c_chisq = nullptr;
   bool overflow = false;             // the device ran out of candidate slots: take the host path for the batch
   uint32_t heavy_reads = 0;          // reads beyond the LDS arrays of kr_place_kernel, done by its second launch (upper bound)
@@ -142,7 +143,7 @@ namespace kr {
 // src/query.hpp:139-152), candidate listing (src/query.cpp:268-281), Brent on the internal candidates and the
 // chi-square of every candidate against the read's closest leaf, all on the device.
 int place_on_device(kr_stream* s, const void* tree_tag, const PlaceTreeArrays& T, const uint32_t* read_len, uint32_t tau,
-                    bool no_filter, PlaceDeviceResult* out);
+                    bool no_filter, double chisq, PlaceDeviceResult* out);
 
 } // namespace kr
 

@@ -839,7 +839,7 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
   T.pn = pt->t.nnodes(), T.nidx = (uint32_t)pt->idx_to_pt.size() - 1;
   T.parent = pt->parent_arr.data(), T.eff = pt->eff.data(), T.elig = pt->elig.data(), T.lo = pt->lo.data(), T.idx_to_pt = pt->idx_to_pt.data();
   kr::PlaceDeviceResult res;
-  int rc = kr::place_on_device(s, pt, T, read_len.data(), p->tau, p->no_filter != 0, &res);
+  int rc = kr::place_on_device(s, pt, T, read_len.data(), p->tau, p->no_filter != 0, p->chisq, &res);
   if (rc) return rc;
   if (res.nreads != nreads) return kr::fail(KR_ERR_ARG, "kr_place_stream: nreads does not match the submitted batch");
   lap("A-C: aggregation, Brent, chi-square on the device + copy back");

@@ -283,16 +283,19 @@ def test_overflow_path_many_leaves(capi, po, synth, tmp_path, monkeypatch, slot_
     assert st3.collect().rows() == first
 
 
-@pytest.mark.parametrize("dbg", ["0", "2048", "8"])
-def test_single_segment_many_leaves_spill_paths(capi, po, synth, tmp_path, monkeypatch, dbg):
+@pytest.mark.parametrize("dbg,n,length", [("0", 160, 150), ("2048", 160, 150), ("8", 160, 150), ("0", 160, 250), ("2048", 160, 250),
+                                          ("0", 1200, 200)])
+def test_single_segment_many_leaves_spill_paths(capi, po, synth, tmp_path, monkeypatch, dbg, n, length):
     """150-bp reads (one 128-position segment: event mode) against 160 close relatives: thousands of events and
     hundreds of (leaf, strand) keys per read -> events spill to global scratch, the epilogue runs several plane
     batches (or, forced by the debug bit, the single batch in global scratch; or, with event mode off, the
-    level-1/level-2 plane tables), the passing-key table spills.  Histograms must be bit-exact in every mode."""
-    n = 160
+    level-1/level-2 plane tables), the passing-key table spills.  Histograms must be bit-exact in every mode.
+    250-bp reads (222 positions = two segments) take the two-segment instantiation of the single-segment layout
+    (8 position bits per event, 256-bit planes, 16-bit counters) through the same spill paths; against 1,200 relatives a
+    200-bp read has 1,200 keys and ~50,000 events: events, key table and passing-key table all live in the wave's global scratch."""
     names = [f"s{i}" for i in range(n)]
     nwk = "(" + ",".join(f"{x}:0.003" for x in names) + ");"
-    g = synth.evolve_genomes(nwk, 5000, seed=17)
+    g = synth.evolve_genomes(nwk, 5000 if n == 160 else 2500, seed=17)
     tsv = synth.write_genomes(g, str(tmp_path / "g"))
     (tmp_path / "t.nwk").write_text(nwk)
     idx = str(tmp_path / "ix")
@@ -300,14 +303,15 @@ def test_single_segment_many_leaves_spill_paths(capi, po, synth, tmp_path, monke
     hx = capi.HostIndex(idx)
     dx = hx.upload(0)
     ox = po.Index(idx)
-    bases, offs, rn = synth.sample_reads(g, 300, seed=9)
+    nreads = 300 if n == 160 else 120
+    bases, offs, rn = synth.sample_reads(g, nreads, seed=9, length=length)
     ref = ox.dist(bases, offs, rn, po.params(collect=7))
     monkeypatch.setenv("KR_DEBUG_SKIP", dbg)
-    st = dx.stream(max_reads=300, max_bases=len(bases), max_records=300 * 2 * n)
+    st = dx.stream(max_reads=nreads, max_bases=len(bases), max_records=nreads * 2 * n)
     st.submit(bases, offs, capi.KR_TAP_ACCS)
     res = st.collect()
     acc = ref["accs"][ref["accs"]["passed"] == 1]
-    assert len(acc) > 300 * 100  # the point of the test: many keys per read
+    assert len(acc) > nreads * (100 if n == 160 else 1000)  # the point of the test: many keys per read
     want = sorted(zip(acc["read"].tolist(), ((acc["se"] << 1) | acc["strand"]).tolist(), [tuple(x[:5]) for x in acc["hist"].tolist()]))
     got = sorted(zip(res.rec_read.tolist(), res.rec_key.tolist(), [tuple(x) for x in res.rec_hist.tolist()]))
     assert got == want
