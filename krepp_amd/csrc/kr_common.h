@@ -125,6 +125,7 @@ struct PlaceTreeArrays {
   const uint8_t* elig = nullptr;    // [pn + 1] nchildren == eff_nchildren && nchildren != 1 (src/query.cpp:270)
   const uint32_t* lo = nullptr;     // [pn + 1] smallest node number in the subtree of q
   const uint32_t* idx_to_pt = nullptr; // [nidx + 1]
+  const uint32_t* depth = nullptr;  // [pn + 1] number of ancestors of q
 };
 struct PlaceDeviceResult { // page-locked host arrays owned by the stream, valid until its next place call / batch
   uint32_t nreads = 0;

@@ -34,7 +34,7 @@ struct kr_place_tree {
   std::vector<uint8_t> kinds;     // node_kind array for kr_index_upload
   uint32_t root = 0;
   // flat arrays for the device back end (kr::place_on_device): parent, subtree start, candidate eligibility
-  std::vector<uint32_t> parent_arr, lo;
+  std::vector<uint32_t> parent_arr, lo, depth; // depth: number of ancestors (post-order numbering: parents after children)
   std::vector<uint8_t> elig;
   bool postorder = false; // every subtree is the node range [lo[q], q]: what the device kernel's ancestor listing needs
 };
@@ -352,6 +352,12 @@ void finish_tree(kr_place_tree& ptr, const kr_index_view& v, bool mapped, bool d
     pt->elig[se] = (nch == pt->eff[se] && nch != 1) ? 1 : 0; // src/query.cpp:270
     if (par && par <= se) pt->postorder = false;
   }
+  pt->depth.assign(pn + 1, 0);
+  if (pt->postorder)
+    for (uint32_t se = pn; se >= 1; --se) { // parents have the larger numbers: depths flow downwards
+      const uint32_t par = pt->parent_arr[se];
+      pt->depth[se] = par ? pt->depth[par] + 1u : 0u;
+    }
   if (pt->postorder) {
     for (uint32_t se = 1; se <= pn; ++se) { // children precede parents: sizes and range starts flow upwards
       const uint32_t par = pt->parent_arr[se];
@@ -837,7 +843,7 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
   });
   kr::PlaceTreeArrays T;
   T.pn = pt->t.nnodes(), T.nidx = (uint32_t)pt->idx_to_pt.size() - 1;
-  T.parent = pt->parent_arr.data(), T.eff = pt->eff.data(), T.elig = pt->elig.data(), T.lo = pt->lo.data(), T.idx_to_pt = pt->idx_to_pt.data();
+  T.parent = pt->parent_arr.data(), T.eff = pt->eff.data(), T.elig = pt->elig.data(), T.lo = pt->lo.data(), T.idx_to_pt = pt->idx_to_pt.data(), T.depth = pt->depth.data();
   kr::PlaceDeviceResult res;
   int rc = kr::place_on_device(s, pt, T, read_len.data(), p->tau, p->no_filter != 0, p->chisq, &res);
   if (rc) return rc;
