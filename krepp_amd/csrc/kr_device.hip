@@ -40,6 +40,7 @@
 //   kr_dev_scan_pipe.inc   kernel 1 for slotted tables as a software pipeline across probe groups
 //   kr_dev_expand.inc      accumulator tables, leaf events, colour classes and colour expansion (kernel 2 only)
 //   kr_dev_accumulate.inc  kernel 2: event epilogue, plane tables, records
+//   kr_dev_tiles.inc       long sequences across waves: tiles of a host batch, their merge per key, the real reads' results
 //   kr_dev_likelihood.inc  likelihood, Brent, de-duplication, selection kernels
 //   kr_dev_place.inc       back end of `place`: ancestor accumulation, candidates, their likelihoods (kr_place_kernel)
 //   kr_dev_debug.inc       debug / tap kernels and the re-layout kernels of kr_index_upload
@@ -77,6 +78,7 @@ namespace {
 #include "kr_dev_scan_pipe.inc"
 #include "kr_dev_expand.inc"
 #include "kr_dev_accumulate.inc"
+#include "kr_dev_tiles.inc"
 #include "kr_dev_likelihood.inc"
 #include "kr_dev_place.inc"
 #include "kr_dev_debug.inc"

@@ -219,13 +219,14 @@ def test_long_reads_and_ragged_batches(capi, po, toy, toy_genomes):
         _, r0 = gpu_dist(capi, dx, bases, offs, 0, **pkw)
         assert_rows_close(r0.rows(), want_rows)
         assert r0.rec_hist is None
-    os.environ["KR_LANE_MIN_READS"], os.environ["KR_LANES"] = "4", "2"
+    # (the two longest sequences are submitted as tiles above: tests/test_gpu_long_sequences.py; a tiled batch is one lane)
+    os.environ["KR_LANE_MIN_READS"], os.environ["KR_LANES"], os.environ["KR_NO_TILES"] = "4", "2", "1"
     try:
         stl, rl = gpu_dist(capi, dx, bases, offs, 0, no_filter=0)
         assert stl.timing().lanes == 2
         assert_rows_close(rl.rows(), rows_of_oracle(ox.dist(bases, offs, names, po.params(collect=0, no_filter=0))))
     finally:
-        os.environ.pop("KR_LANE_MIN_READS"), os.environ.pop("KR_LANES")
+        os.environ.pop("KR_LANE_MIN_READS"), os.environ.pop("KR_LANES"), os.environ.pop("KR_NO_TILES")
 
 
 @pytest.mark.parametrize("slot_log2w,dbg", [("0", "8192"), ("5", "8192"), ("6", "8192"), ("6", "0"), ("8", "0")])
