@@ -191,7 +191,15 @@ KR_API void kr_stream_destroy(kr_stream*);
  * pinned-host staging + hipMemcpyAsync: a HOST batch of >= 2 * 65,536 reads is cut into up to KR_LANES (env, default 2)
  * contiguous read ranges, each with its own HIP stream: the H2D copy, the kernels and (in kr_batch_collect) the
  * D2H copy of one range overlap with those of the other.  Results do not depend on the number of lanes.  Across
- * batches, two kr_streams used in turn overlap one batch's copies with the other's kernels (bench.py, the CLI). */
+ * batches, two kr_streams used in turn overlap one batch's copies with the other's kernels (bench.py, the CLI).
+ *
+ * Long sequences (contigs, genomes): the reference scans a sequence serially (search_mers, src/query.cpp:40-94).  A HOST
+ * batch that holds sequences of more than 1,024 k-mer positions is submitted as tiles of 128 positions (neighbours overlap by
+ * k - 1 bases), which run on as many waves as there are tiles; the tiles' histograms are added per (reference, strand) and the
+ * hdist_filt test is applied with the sequence's minimum, so the results are those of the serial scan (identical records, in
+ * the same order).  The tiled form needs max_reads >= the number of tiles + the number of other reads (else, or for batches
+ * already in HBM, or with KR_TAP_HITS, a sequence is one wave's work as before); a tiled batch whose tiles' records overflow
+ * the device buffers is run again untiled by kr_batch_wait / kr_batch_collect.  The views always describe the caller's reads. */
 KR_API int kr_batch_submit(kr_stream*, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads,
                            uint32_t flags);
 KR_API int kr_batch_wait(kr_stream*);
