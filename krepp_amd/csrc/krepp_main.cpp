@@ -260,7 +260,8 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
     kr_stream* st = nullptr;
     uint64_t max_records = (uint64_t)max_reads * (place ? 128 : 64);
     if (const char* e = getenv("KR_DEBUG_CLI_RECORDS")) max_records = strtoull(e, nullptr, 10); // tests: force the split-and-retry path
-    if (kr_stream_create(dix[g], (place || seek) ? &pfront : &p, max_reads, max_bases, max_records, &st)) {
+    // (four times the reads of a batch: a batch of contigs is submitted as tiles of 128 k-mer positions, include/krepp_amd.h)
+    if (kr_stream_create(dix[g], (place || seek) ? &pfront : &p, 4 * max_reads, max_bases, max_records, &st)) {
       std::lock_guard<std::mutex> lk(mu);
       worker_err = kr_last_error();
       cv_done.notify_all();

@@ -125,3 +125,29 @@ def test_a_tiled_batch_that_overflows_is_run_again_untiled(capi, po, toy, toy_ge
     assert_rows_close(res.rows(), rows_of_oracle(ref))
     st.submit(bases, offs)  # and the stream is as good as new
     assert_rows_close(st.collect().rows(), rows_of_oracle(ref))
+
+
+def test_a_stream_with_room_for_some_of_the_tiles_tiles_what_fits(capi, po, toy, toy_genomes):
+    """A long sequence of nt tiles takes nt - 1 reads more than the batch has; a stream created for fewer reads than the tiles of
+    all the batch's sequences tiles those that fit (in order) and leaves the others to one wave each: same results."""
+    hx, dx, ox = toy
+    rng = np.random.default_rng(21)
+    names_g = list(toy_genomes)
+    seqs = []
+    for L in (5000, 150, 5000, 3000, 150, 5000):  # 39, 39, 24 and 39 tiles: 38, 38, 23 and 38 reads more than the batch has
+        gname = names_g[int(rng.integers(0, len(names_g)))]
+        o = int(rng.integers(0, 20000 - L + 1))
+        seqs.append(toy_genomes[gname][o:o + L].tobytes())
+    bases = np.frombuffer(b"".join(seqs), np.uint8)
+    offs = np.cumsum([0] + [len(s) for s in seqs]).astype(np.uint64)
+    names = [f"s{i}" for i in range(len(seqs))]
+    ref = ox.dist(bases, offs, names, po.params(collect=7))
+    acc = ref["accs"][ref["accs"]["passed"] == 1]
+    want = sorted(zip(acc["read"].tolist(), ((acc["se"] << 1) | acc["strand"]).tolist(), [tuple(x[:5]) for x in acc["hist"].tolist()]))
+    for max_reads in (70, 48, 43, 6):  # room for: the first and the 3 kb one; the first; the 3 kb one alone; none
+        st = dx.stream(params=capi.default_params(), max_reads=max_reads, max_bases=len(bases) + 64, max_records=1 << 18)
+        st.submit(bases, offs, capi.KR_TAP_ACCS)
+        res = st.collect()
+        assert accs_of(res) == want, max_reads
+        assert_rows_close(res.rows(), rows_of_oracle(ref))
+        assert st.readtaps(len(names)).tolist() == ref["reads"]["hdist_filt"].tolist()
