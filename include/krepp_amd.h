@@ -128,6 +128,10 @@ KR_API int kr_index_export(const kr_index*, void* desc, uint64_t* desc_bytes, kr
 KR_API int kr_index_import(const void* desc, uint64_t desc_bytes, int device, kr_index** out, kr_index_buffer* bufs,
                            uint32_t* nbufs);
 KR_API uint64_t kr_index_device_bytes(const kr_index*);
+/* Words (4 bytes) per slot of the slotted copy of the bucket heads the upload made for this index, 0 when it kept the packed
+ * table only (sparse tables; INTEGRATION.md "Memory and tuning knobs").  Says which scan kernel serves the index:
+ * kr_scan_pipe_kernel_t (slotted) or kr_scan_kernel_t (packed). */
+KR_API uint32_t kr_index_slot_words(const kr_index*);
 
 /* Replicate an uploaded index into the HBM of `ndev` more devices of this node by RCCL broadcast
  * (ncclBroadcast per flat buffer, one communicator over the root's device and the targets, xGMI):

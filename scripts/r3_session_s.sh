@@ -23,3 +23,9 @@ wait $BP
 grep "stream-variance" gpurun_out/r3s_bench2.err
 tail -40 gpurun_out/r3s_smi.txt
 python3 -m pytest tests/test_gpu_long_sequences.py -x -q 2>&1 | tail -3
+# sequences between a read and a contig: where should tiling start?
+for L in 400 600 1000; do
+  NC=$((30000000 / L))
+  echo "== $L bp x $NC, tiles from 1,024 positions (default: none of these are tiled)"; python3 scripts/time_contigs.py $L $NC 2>&1 | tail -3
+  echo "== $L bp x $NC, tiles from 256 positions"; KR_TILE_MIN_POS=256 python3 scripts/time_contigs.py $L $NC 2>&1 | tail -3
+done

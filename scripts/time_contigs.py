@@ -19,7 +19,8 @@ rng = np.random.default_rng(3)
 gl = list(g.values())
 seqs = []
 for i in range(nc):  # contigs: stretches of the references with 1 % substitutions
-    s = gl[i % len(gl)][:L].copy()
+    o = int(rng.integers(0, 400_000 - L + 1))
+    s = gl[i % len(gl)][o:o + L].copy()
     mut = rng.random(len(s)) < 0.01
     s[mut] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(mut.sum()))]
     seqs.append(s)

@@ -37,7 +37,7 @@ from krepp_amd import srcinfo
 bi = srcinfo.build_info()
 commit = bi.get("scan_commit")
 out = {
-    "kernel": "kr_scan_kernel", "workload": b["config"]["workload"], "table": "slotted" if slotted else "packed",
+    "kernel": b["roofline"].get("kernel", "kr_scan_kernel"), "workload": b["config"]["workload"], "table": "slotted" if slotted else "packed",
     "profile": tag, "commit": commit, "head_at_build": bi.get("head"), "scan_src_sha": bi["scan_src_sha"],
     "scan_sources": list(srcinfo.SCAN_SOURCES), "scan_ms": b["kernel_ms"]["scan"],
     "reads_per_launch": n, "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
