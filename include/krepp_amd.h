@@ -254,6 +254,11 @@ typedef struct kr_readtap {
 } kr_readtap;
 KR_API int kr_batch_readtaps(kr_stream*, const kr_readtap** taps);
 
+/* Experiments (the scan kernel's launch-time levels): give one group of a stream's device buffers a new
+ * address -- 0: item list, 1: per-read arrays, 2: counters and cursors, 3: records and de-duplication table -- or its kernels a
+ * new HIP stream (4).  Between batches only; results are unaffected. */
+KR_API int kr_debug_stream_move(kr_stream*, int which);
+
 /* Front-end tap: rix / enc32 / residue test for every (k-mer, strand) of one batch,
  * laid out [read][kpos][strand] with `stride` = max k-mers per read; valid==0 marks
  * positions whose window holds a non-ACGT byte or runs past the read. */
