@@ -258,6 +258,8 @@ KR_API int kr_batch_readtaps(kr_stream*, const kr_readtap** taps);
  * address -- 0: item list, 1: per-read arrays, 2: counters and cursors, 3: records and de-duplication table -- or its kernels a
  * new HIP stream (4).  Between batches only; results are unaffected. */
 KR_API int kr_debug_stream_move(kr_stream*, int which);
+/* ... and where they are: item list, counters, cursors, rd_off, rd_it_off, rd_filt, rec_key, de-duplication table. */
+KR_API int kr_debug_stream_addrs(kr_stream*, uint64_t* out8);
 
 /* Front-end tap: rix / enc32 / residue test for every (k-mer, strand) of one batch,
  * laid out [read][kpos][strand] with `stride` = max k-mers per read; valid==0 marks

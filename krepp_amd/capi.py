@@ -87,7 +87,7 @@ EXPORTS = [
     "kr_index_upload", "kr_index_free", "kr_index_export", "kr_index_import", "kr_index_device_bytes", "kr_index_slot_words", "kr_index_broadcast",
     "kr_params_default", "kr_stream_create", "kr_stream_destroy", "kr_batch_submit", "kr_batch_wait",
     "kr_batch_collect", "kr_batch_collect_device", "kr_batch_hits", "kr_batch_readtaps",
-    "kr_debug_front_end", "kr_debug_stream_move", "kr_debug_brent", "kr_debug_colour_classes", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
+    "kr_debug_front_end", "kr_debug_stream_move", "kr_debug_stream_addrs", "kr_debug_brent", "kr_debug_colour_classes", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
     "kr_place_tree_create", "kr_place_tree_create_lineage", "kr_place_tree_nnodes", "kr_place_summary_add",
     "kr_place_summary_text", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_stream", "kr_place_frame", "kr_place_counters",
     "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_format_dist", "kr_free", "kr_host_alloc", "kr_host_free",
@@ -137,6 +137,7 @@ def load():
     lib.kr_index_device_bytes.restype = C.c_uint64
     lib.kr_index_slot_words.argtypes = [vp]
     lib.kr_debug_stream_move.argtypes = [vp, C.c_int]
+    lib.kr_debug_stream_addrs.argtypes = [vp, u64p]
     lib.kr_index_slot_words.restype = C.c_uint32
     lib.kr_params_default.argtypes = [C.POINTER(KrParams)]
     lib.kr_params_default.restype = None
@@ -457,6 +458,11 @@ class Stream:
     def debug_move(self, which):
         """experiments: one group of the stream's device buffers at a new address (kr_debug_stream_move)"""
         check(self.lib.kr_debug_stream_move(self.h, which))
+
+    def debug_addrs(self):
+        a = (C.c_uint64 * 8)()
+        check(self.lib.kr_debug_stream_addrs(self.h, a))
+        return dict(zip(("items", "counters", "cursors", "rd_off", "rd_it_off", "rd_filt", "rec_key", "dd"), [int(x) for x in a]))
 
     def timing(self):
         t = KrTiming()
