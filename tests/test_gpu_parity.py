@@ -500,6 +500,29 @@ def test_large_batch_properties(capi, toy, toy_genomes, synth):
     assert r1.rows() + [(r + half, s, d) for r, s, d in r2.rows()] == rows
 
 
+def test_where_a_streams_buffers_lie_does_not_change_results(capi, toy, toy_genomes, synth, monkeypatch):
+    """kr_debug_stream_move (the experiments on the scan's launch-time levels) gives one group of a stream's
+    device buffers a new address, or its kernels a new HIP stream, between batches; KR_HBM_CONTIGUOUS asks the driver for
+    physically contiguous buffers: same rows every time."""
+    hx, dx, ox = toy
+    bases, offs, _ = synth.sample_reads(toy_genomes, 30_000, seed=78)
+    st, res = gpu_dist(capi, dx, bases, offs)
+    rows = res.rows()
+    a0 = st.debug_addrs()
+    for which in (0, 1, 2, 3, 4):
+        st.debug_move(which)
+        st.submit(bases, offs)
+        assert st.collect().rows() == rows, which
+    a1 = st.debug_addrs()
+    assert all(a1[k] != a0[k] for k in ("items", "counters", "cursors", "rd_off", "rec_key", "dd"))
+    with pytest.raises(capi.KrError):
+        st.debug_move(5)
+    monkeypatch.setenv("KR_HBM_CONTIGUOUS", "3")
+    dx2 = hx.upload(0)
+    _, res2 = gpu_dist(capi, dx2, bases, offs)
+    assert res2.rows() == rows
+
+
 def test_lanes_do_not_change_results(capi, toy, toy_genomes, synth, monkeypatch):
     """A batch cut into several lanes (own HIP stream, own H2D/D2H copies, slices of the result arrays) returns what one
     lane returns: records, histograms, rows, report text; host view, device view, KR_ROWS_ONLY and KR_BASES_PINNED."""
