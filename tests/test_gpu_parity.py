@@ -502,8 +502,8 @@ def test_large_batch_properties(capi, toy, toy_genomes, synth):
 
 def test_where_a_streams_buffers_lie_does_not_change_results(capi, toy, toy_genomes, synth, monkeypatch):
     """kr_debug_stream_move (the experiments on the scan's launch-time levels) gives one group of a stream's
-    device buffers a new address, or its kernels a new HIP stream, between batches; KR_HBM_CONTIGUOUS asks the driver for
-    physically contiguous buffers: same rows every time."""
+    device buffers a new address, or its kernels a new HIP stream, between batches: same rows every time.  And nothing depends
+    on what a fresh device buffer holds (KR_DEBUG_POISON fills every buffer of a new stream with 0xA5)."""
     hx, dx, ox = toy
     bases, offs, _ = synth.sample_reads(toy_genomes, 30_000, seed=78)
     st, res = gpu_dist(capi, dx, bases, offs)
@@ -517,10 +517,12 @@ def test_where_a_streams_buffers_lie_does_not_change_results(capi, toy, toy_geno
     assert all(a1[k] != a0[k] for k in ("items", "counters", "cursors", "rd_off", "rec_key", "dd"))
     with pytest.raises(capi.KrError):
         st.debug_move(5)
-    monkeypatch.setenv("KR_HBM_CONTIGUOUS", "3")
-    dx2 = hx.upload(0)
-    _, res2 = gpu_dist(capi, dx2, bases, offs)
-    assert res2.rows() == rows
+    st.close()
+    monkeypatch.setenv("KR_DEBUG_POISON", "all")
+    for flags in (0, capi.KR_TAP_ACCS):
+        st2, res2 = gpu_dist(capi, dx, bases, offs, flags)
+        assert res2.rows() == rows
+        st2.close()
 
 
 def test_lanes_do_not_change_results(capi, toy, toy_genomes, synth, monkeypatch):
