@@ -261,6 +261,14 @@ KR_API int kr_debug_stream_move(kr_stream*, int which);
 /* ... and where they are: item list, counters, cursors, rd_off, rd_it_off, rd_filt, rec_key, de-duplication table. */
 KR_API int kr_debug_stream_addrs(kr_stream*, uint64_t* out8);
 
+/* Item-list placement: a stream that is given batches of a million reads or more allocates its item list
+ * (the scan kernel's output) up to KR_ITEM_PLACEMENT_TRIALS more times (environment, default 3, 0 = never) during its first
+ * batches -- one spare list at a time -- and keeps the allocation the scan kernel ran fastest on; the kernel's launch time depends
+ * on the physical pages behind the list (40.5 against 46.5 ms per 8 M reads), which only a new allocation changes.  Results are
+ * unaffected.  This call reports what the stream did: allocations tried, how many of them replaced the one before, and the scan
+ * time per read on the list it kept. */
+KR_API int kr_debug_item_placement(kr_stream*, uint32_t* tried, uint32_t* kept, double* best_ns_per_read);
+
 /* Front-end tap: rix / enc32 / residue test for every (k-mer, strand) of one batch,
  * laid out [read][kpos][strand] with `stride` = max k-mers per read; valid==0 marks
  * positions whose window holds a non-ACGT byte or runs past the read. */

@@ -87,7 +87,7 @@ EXPORTS = [
     "kr_index_upload", "kr_index_free", "kr_index_export", "kr_index_import", "kr_index_device_bytes", "kr_index_slot_words", "kr_index_broadcast",
     "kr_params_default", "kr_stream_create", "kr_stream_destroy", "kr_batch_submit", "kr_batch_wait",
     "kr_batch_collect", "kr_batch_collect_device", "kr_batch_hits", "kr_batch_readtaps",
-    "kr_debug_front_end", "kr_debug_stream_move", "kr_debug_stream_addrs", "kr_debug_brent", "kr_debug_colour_classes", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
+    "kr_debug_front_end", "kr_debug_stream_move", "kr_debug_stream_addrs", "kr_debug_item_placement", "kr_debug_brent", "kr_debug_colour_classes", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
     "kr_place_tree_create", "kr_place_tree_create_lineage", "kr_place_tree_nnodes", "kr_place_summary_add",
     "kr_place_summary_text", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_stream", "kr_place_frame", "kr_place_counters",
     "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_format_dist", "kr_free", "kr_host_alloc", "kr_host_free",
@@ -138,6 +138,7 @@ def load():
     lib.kr_index_slot_words.argtypes = [vp]
     lib.kr_debug_stream_move.argtypes = [vp, C.c_int]
     lib.kr_debug_stream_addrs.argtypes = [vp, u64p]
+    lib.kr_debug_item_placement.argtypes = [vp, u32p, u32p, C.POINTER(C.c_double)]
     lib.kr_index_slot_words.restype = C.c_uint32
     lib.kr_params_default.argtypes = [C.POINTER(KrParams)]
     lib.kr_params_default.restype = None
@@ -458,6 +459,12 @@ class Stream:
     def debug_move(self, which):
         """experiments: one group of the stream's device buffers at a new address (kr_debug_stream_move)"""
         check(self.lib.kr_debug_stream_move(self.h, which))
+
+    def item_placement(self):
+        """(allocations of the item list tried, how many replaced the one before, scan ns per read on the one kept)"""
+        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_double(0)
+        check(self.lib.kr_debug_item_placement(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"tried": a.value, "kept": b.value, "scan_ns_per_read": c.value}
 
     def debug_addrs(self):
         a = (C.c_uint64 * 8)()
