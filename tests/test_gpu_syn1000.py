@@ -110,16 +110,16 @@ def test_syn1000_10gb_index_vs_oracle_and_full_batch_properties(capi, po, synth,
         # a stream given large one-lane batches tries other allocations of its item list during its first batches and keeps
         # the one the scan ran fastest on: same rows on every one of them
         monkeypatch.setenv("KR_LANES", "1")
-        for trials in ("3", "0"):
+        for trials in (("3", "0") if slot_log2w is None else ()):
             monkeypatch.setenv("KR_ITEM_PLACEMENT_TRIALS", trials)
             stf = dx.stream(max_reads=n, max_bases=len(bases), max_records=n * 64)
-            for _ in range(5):
+            for _ in range(4 if trials == "3" else 1):
                 assert (canon(run(bases, offs)) == rows).all()
             ip = stf.item_placement()
             assert ip["tried"] == int(trials) and ip["kept"] <= ip["tried"] and (ip["scan_ns_per_read"] > 0) == (trials != "0")
             stf.close()
         monkeypatch.delenv("KR_LANES")
-        monkeypatch.delenv("KR_ITEM_PLACEMENT_TRIALS")
+        monkeypatch.delenv("KR_ITEM_PLACEMENT_TRIALS", raising=False)
     finally:
         dx.close()
         hx.close()
