@@ -151,3 +151,14 @@ def test_a_stream_with_room_for_some_of_the_tiles_tiles_what_fits(capi, po, toy,
         assert accs_of(res) == want, max_reads
         assert_rows_close(res.rows(), rows_of_oracle(ref))
         assert st.readtaps(len(names)).tolist() == ref["reads"]["hdist_filt"].tolist()
+
+
+def test_fuzzed_mixes_of_reads_and_contigs(capi):
+    """scripts/fuzz_long.py: random batches of reads, sequences around the tiling threshold and around multiples of the tile length,
+    chimeric contigs on either strand with substitutions and N runs, on streams with room for all, some or none of the tiles:
+    histograms, hdist_filt and report text against the oracle, with and without the histogram tap."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_long.py"), "8"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "mismatching batches: 0" in out.stdout, out.stdout[-2000:]
