@@ -201,9 +201,10 @@ KR_API void kr_stream_destroy(kr_stream*);
  * batch that holds sequences of more than 1,024 k-mer positions is submitted as tiles of 128 positions (neighbours overlap by
  * k - 1 bases), which run on as many waves as there are tiles; the tiles' histograms are added per (reference, strand) and the
  * hdist_filt test is applied with the sequence's minimum, so the results are those of the serial scan (identical records, in
- * the same order).  The tiled form needs max_reads >= the number of tiles + the number of other reads (else, or for batches
- * already in HBM, or with KR_TAP_HITS, a sequence is one wave's work as before); a tiled batch whose tiles' records overflow
- * the device buffers is run again untiled by kr_batch_wait / kr_batch_collect.  The views always describe the caller's reads. */
+ * the same order).  A tile counts as a read against max_reads: the sequences whose tiles fit the stream are tiled, in order
+ * (the others, and every sequence of a batch already in HBM or submitted with KR_TAP_HITS, are one wave's work as before); a
+ * tiled batch whose tiles' records overflow the device buffers is run again untiled by kr_batch_wait / kr_batch_collect.  The
+ * views always describe the caller's reads. */
 KR_API int kr_batch_submit(kr_stream*, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads,
                            uint32_t flags);
 KR_API int kr_batch_wait(kr_stream*);
