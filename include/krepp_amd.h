@@ -139,7 +139,10 @@ KR_API uint32_t kr_index_slot_words(const kr_index*);
  * on the query path.  Replaces what the reference does once per process, TargetIndex::load_index
  * (src/krepp.cpp:92-106), for the GPUs after the first.  replicas[i] lives on devices[i] and is freed
  * with kr_index_free; devices are distinct; a device equal to the root's gives a second copy in the
- * same HBM (one-rank communicator).  RCCL (librccl.so.1) is loaded on first use. */
+ * same HBM (one-rank communicator).  RCCL (librccl.so.1) is loaded on first use.  RCCL may print a version
+ * banner on stdout when the first communicator is made: the library never touches the process's file
+ * descriptors, so an application whose stdout carries the report redirects it around this call itself,
+ * before its writer threads start. */
 KR_API int kr_index_broadcast(const kr_index* root, int ndev, const int* devices, kr_index** replicas);
 
 /* ------------------------------------------------------------------------- */

@@ -24,6 +24,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #define KREPP_VERSION "v0.8.3"
@@ -215,7 +216,19 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
   if (ngpus > 1) {
     std::vector<int> devs;
     for (int g = 1; g < ngpus; ++g) devs.push_back(dev0 + g);
-    if (kr_index_broadcast(dix[0], ngpus - 1, devs.data(), dix.data() + 1)) error_exit(kr_last_error());
+    // RCCL may print a version banner on stdout when its first communicator is made; stdout is where the report rows go
+    // (src/krepp.cpp:372-382).  This process is still single-threaded here (the workers start below), so pointing file
+    // descriptor 1 at stderr for the duration of the call is safe -- the application's decision, not the library's.
+    fflush(stdout);
+    const int saved_out = dup(1);
+    if (saved_out >= 0) (void)dup2(2, 1);
+    const int brc = kr_index_broadcast(dix[0], ngpus - 1, devs.data(), dix.data() + 1);
+    if (saved_out >= 0) {
+      fflush(stdout);
+      (void)dup2(saved_out, 1);
+      close(saved_out);
+    }
+    if (brc) error_exit(kr_last_error());
   }
   if (seek) fprintf(stderr, "Seeking query sequences in the sketch...\n");
   if (!place && !seek) fprintf(stderr, "Estimating distances between given sequences and references...\n");

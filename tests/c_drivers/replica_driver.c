@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "krepp_amd.h"
 
@@ -33,7 +34,18 @@ int main(int argc, char** argv)
   CHECK(kr_host_index_view(hx, &view));
   CHECK(kr_index_upload(&view, 0, KR_VIEW_HOST, &root));
   int dev = 0;
-  CHECK(kr_index_broadcast(root, 1, &dev, &rep));
+  /* RCCL may print a version banner on stdout when its first communicator is made; the library leaves file descriptors
+   * alone, so the application (single-threaded here) points fd 1 at stderr around the call, like krepp_main.cpp does */
+  fflush(stdout);
+  int saved_out = dup(1);
+  if (saved_out >= 0) dup2(2, 1);
+  int brc = kr_index_broadcast(root, 1, &dev, &rep);
+  if (saved_out >= 0) {
+    fflush(stdout);
+    dup2(saved_out, 1);
+    close(saved_out);
+  }
+  CHECK(brc);
   if (kr_index_device_bytes(rep) != kr_index_device_bytes(root)) {
     fprintf(stderr, "replica size differs\n");
     return 1;

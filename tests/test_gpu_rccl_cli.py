@@ -26,7 +26,8 @@ def test_plain_c_process_replicates_through_rccl_and_queries_the_replica(po, toy
     names, bases, offs = toy_reads
     want = po.Index(toy_index_dir).dist(bases, offs, names, po.params(collect=4))["text"]
     # RCCL's version banner ("RCCL version : ...", "Librccl path : ...") goes to stdout when the first communicator is made;
-    # kr_index_broadcast points fd 1 at stderr for that call, so stdout carries the rows and nothing else
+    # the driver (the application, single-threaded at that point) points fd 1 at stderr around kr_index_broadcast -- the library
+    # itself never touches file descriptors -- so stdout carries the rows and nothing else
     assert r.stdout == want
     banner = [l for l in r.stderr.splitlines() if l.startswith("Librccl path")]
     assert all("torch" not in l for l in banner), r.stderr
