@@ -132,6 +132,10 @@ KR_API uint64_t kr_index_device_bytes(const kr_index*);
  * table only (sparse tables; INTEGRATION.md "Memory and tuning knobs").  Says which scan kernel serves the index:
  * kr_scan_pipe_kernel_t (slotted) or kr_scan_kernel_t (packed). */
 KR_API uint32_t kr_index_slot_words(const kr_index*);
+/* The slot format itself: 0 packed table only; 5 / 6 / 7 / 8 slots of 32 / 64 / 128 / 48 four-byte words (kr_scan_pipe_kernel_t);
+ * 9 FILTER slots -- two 128-byte lines of 24-bit codes per row, one line per probe for most buckets, candidates verified by
+ * the accumulate kernel (kr_scan_filt_kernel_t; replaces the linear bucket scan of src/query.cpp:361-368). */
+KR_API uint32_t kr_index_slot_format(const kr_index*);
 
 /* Replicate an uploaded index into the HBM of `ndev` more devices of this node by RCCL broadcast
  * (ncclBroadcast per flat buffer, one communicator over the root's device and the targets, xGMI):

@@ -84,7 +84,7 @@ class KrBuildParams(C.Structure):
 EXPORTS = [
     "kr_host_index_load", "kr_host_sketch_load", "kr_format_seek", "kr_build_sketch", "kr_host_index_free", "kr_host_index_view", "kr_host_index_node_name",
     "kr_host_index_node_label", "kr_host_index_node_parent", "kr_host_index_node_blen",
-    "kr_index_upload", "kr_index_free", "kr_index_export", "kr_index_import", "kr_index_device_bytes", "kr_index_slot_words", "kr_index_broadcast",
+    "kr_index_upload", "kr_index_free", "kr_index_export", "kr_index_import", "kr_index_device_bytes", "kr_index_slot_words", "kr_index_slot_format", "kr_index_broadcast",
     "kr_params_default", "kr_stream_create", "kr_stream_destroy", "kr_batch_submit", "kr_batch_wait",
     "kr_batch_collect", "kr_batch_collect_device", "kr_batch_hits", "kr_batch_readtaps",
     "kr_debug_front_end", "kr_debug_stream_move", "kr_debug_stream_addrs", "kr_debug_item_placement", "kr_debug_brent", "kr_debug_colour_classes", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
@@ -136,6 +136,8 @@ def load():
     lib.kr_index_broadcast.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     lib.kr_index_device_bytes.restype = C.c_uint64
     lib.kr_index_slot_words.argtypes = [vp]
+    lib.kr_index_slot_format.argtypes = [vp]
+    lib.kr_index_slot_format.restype = C.c_uint32
     lib.kr_debug_stream_move.argtypes = [vp, C.c_int]
     lib.kr_debug_stream_addrs.argtypes = [vp, u64p]
     lib.kr_debug_item_placement.argtypes = [vp, u32p, u32p, C.POINTER(C.c_double)]
@@ -318,6 +320,10 @@ class DeviceIndex:
     @property
     def slot_words(self):
         return int(self.lib.kr_index_slot_words(self.h))
+
+    @property
+    def slot_format(self):
+        return int(self.lib.kr_index_slot_format(self.h))
 
     def stream(self, params=None, max_reads=1 << 16, max_bases=None, max_records=0):
         return Stream(self, params or default_params(), max_reads, max_bases or max_reads * 160, max_records)

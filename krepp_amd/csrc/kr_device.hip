@@ -38,6 +38,7 @@
 //   kr_dev_common.inc      constants, device structs and helpers shared by the kernels
 //   kr_dev_scan.inc        kernel 1: probe list, bucket scan, hit items
 //   kr_dev_scan_pipe.inc   kernel 1 for slotted tables as a software pipeline across probe groups
+//   kr_dev_scan_filt.inc   kernel 1 for FILTER slots (format 9): one 128-byte line of 24-bit codes per probe, candidates verified in kernel 2
 //   kr_dev_expand.inc      accumulator tables, leaf events, colour classes and colour expansion (kernel 2 only)
 //   kr_dev_accumulate.inc  kernel 2: event epilogue, plane tables, records
 //   kr_dev_tiles.inc       long sequences across waves: tiles of a host batch, their merge per key, the real reads' results
@@ -76,6 +77,7 @@ namespace {
 #include "kr_dev_common.inc"
 #include "kr_dev_scan.inc"
 #include "kr_dev_scan_pipe.inc"
+#include "kr_dev_scan_filt.inc"
 #include "kr_dev_expand.inc"
 #include "kr_dev_accumulate.inc"
 #include "kr_dev_tiles.inc"

@@ -2,11 +2,13 @@
 parameters -k 29 -w 35 -h 13, m4r1-frac: 2^25 rows) whose table is inflated to 10 GB resident in HBM — the
 exact index bench.py measures (krepp_amd.synth.inflate_and_upload, same seeds).
 
-Per table layout (the slotted copy of the bucket heads with W = 64 words; with W = 48 words = 192-byte slots, where 7 % of
-the buckets continue in the packed array; and KR_SLOT_LOG2W=0, the packed table only): 20,000 reads against the oracle holding the same table (Index.replace_table) — table hits
+Per table layout (FILTER slots, the default for this table: one 128-byte line of 24-bit codes per probe, candidates verified by
+the accumulate kernel; the slotted copy of the bucket heads with W = 64 words; and KR_SLOT_LOG2W=0, the packed table only): 20,000 reads against the oracle holding the same table (Index.replace_table) — table hits
 (src/query.cpp:352-368, src/index.cpp:160-168) and histograms (src/query.hpp:153-176) bit-exact, DIST within the
 north star's 1e-6 relative — then a full 1,000,000-read batch through the size-independent properties
-(reverse complement, permutation, split).
+(reverse complement, permutation, split); on the default layout the same three properties once more at 4,000,000 reads per
+launch -- the size class of bench.py's timed launches (item lists of hundreds of millions of entries, every cursor range in use)
+-- compared through an order-independent 128-bit checksum of the rows.
 """
 import os
 
@@ -18,7 +20,20 @@ from conftest import assert_rows_close, rows_of_oracle
 pytestmark = pytest.mark.gpu
 
 N_GENOMES, GENOME_LEN, INDEX_GB = 1000, 100_000, 10.0
-N_ORACLE, N_FULL = 20_000, 1_000_000
+N_ORACLE, N_FULL, N_LAUNCH = 20_000, 1_000_000, 4_000_000
+
+
+def rows_checksum(read, se, dbits):
+    """Order-independent checksum of a multiset of (read, se, DIST bits) rows: (sum, xor) of a 64-bit mix of every row."""
+    with np.errstate(over="ignore"):
+        h = read.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + se.astype(np.uint64)
+        h ^= h >> np.uint64(29)
+        h *= np.uint64(0xBF58476D1CE4E5B9)
+        h += dbits.astype(np.uint64)
+        h ^= h >> np.uint64(32)
+        h *= np.uint64(0x94D049BB133111EB)
+        h ^= h >> np.uint64(31)
+        return int(h.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(h)), int(len(h))
 
 
 @pytest.fixture(scope="module")
@@ -39,21 +54,21 @@ def make_reads(synth, genomes, n, seed):
     return np.concatenate(chunks), np.arange(n + 1, dtype=np.uint64) * np.uint64(150)
 
 
-@pytest.mark.parametrize("slot_log2w", [None, "0"], ids=["slotted_w64", "packed"])
+@pytest.mark.parametrize("slot_log2w", ["9", "6", "0"], ids=["filter_slots", "slotted_w64", "packed"])
 def test_syn1000_10gb_index_vs_oracle_and_full_batch_properties(capi, po, synth, syn, monkeypatch, slot_log2w):
     import torch
 
     idx, genomes = syn
-    if slot_log2w is not None:
-        monkeypatch.setenv("KR_SLOT_LOG2W", slot_log2w)
+    monkeypatch.setenv("KR_SLOT_LOG2W", slot_log2w)
     dev = torch.device("cuda", 0)
     hx = capi.HostIndex(idx)
     dx, (inc, cmer) = synth.inflate_and_upload(torch, capi, hx, dev, 0, INDEX_GB)
     try:
         nk = cmer.size // 2
         assert len(inc) == 1 << 25 and nk * 8 >= 0.99 * INDEX_GB * 1e9
-        # slotted: 2^25 rows x 256 B (or 192 B: format 8) of slots on top of the packed table; packed: no slots
-        assert (dx.device_bytes > 18e9) == (slot_log2w is None) and (dx.device_bytes > 16e9) == (slot_log2w != "0")
+        # slotted: 2^25 rows x 256 B of slots on top of the packed table; filter slots: 2^25 x 640 B of slot-ordered colours more; packed: no slots
+        assert dx.slot_format == int(slot_log2w)
+        assert (dx.device_bytes > 38e9) == (slot_log2w == "9") and (dx.device_bytes > 18e9) == (slot_log2w != "0")
         ox = po.Index(idx)
         ox.replace_table(0, inc, cmer)
         del inc, cmer
@@ -110,7 +125,7 @@ def test_syn1000_10gb_index_vs_oracle_and_full_batch_properties(capi, po, synth,
         # a stream given large one-lane batches tries other allocations of its item list during its first batches and keeps
         # the one the scan ran fastest on: same rows on every one of them
         monkeypatch.setenv("KR_LANES", "1")
-        for trials in (("3", "0") if slot_log2w is None else ()):
+        for trials in (("3", "0") if slot_log2w == "6" else ()):
             monkeypatch.setenv("KR_ITEM_PLACEMENT_TRIALS", trials)
             stf = dx.stream(max_reads=n, max_bases=len(bases), max_records=n * 64)
             for _ in range(4 if trials == "3" else 1):
@@ -120,6 +135,32 @@ def test_syn1000_10gb_index_vs_oracle_and_full_batch_properties(capi, po, synth,
             stf.close()
         monkeypatch.delenv("KR_LANES")
         monkeypatch.delenv("KR_ITEM_PLACEMENT_TRIALS", raising=False)
+
+        # ---- 4,000,000 reads per launch (default layout): the same properties at the size class of bench.py's timed launches ----
+        if slot_log2w == "9":
+            n = N_LAUNCH
+            bases, offs = make_reads(synth, genomes, n, seed=6)
+            stl = dx.stream(max_reads=n, max_bases=len(bases), max_records=n * 64)
+
+            def run_sum(b, o, read_map=None, read_add=0):
+                stl.submit(b, o, capi.KR_ROWS_ONLY)
+                r = stl.collect()
+                sel = r.rec_sel.astype(bool)
+                rd = r.rec_read[sel].astype(np.int64)
+                if read_map is not None:
+                    rd = read_map[rd]
+                return rows_checksum(rd + read_add, r.rec_key[sel] >> 1, r.rec_d[sel].view(np.uint64))
+
+            base_sum = run_sum(bases, offs)
+            assert base_sum[2] > 20 * n
+            assert run_sum(synth.COMP[bases.reshape(n, 150)[:, ::-1]].reshape(-1), offs) == base_sum, "4 M reads: reverse complement changes the rows"
+            perm = np.random.default_rng(2).permutation(n)
+            assert run_sum(bases.reshape(n, 150)[perm].reshape(-1), offs, read_map=perm) == base_sum, "4 M reads: permutation changes the rows"
+            half = n // 2
+            a = run_sum(bases[: half * 150], offs[: half + 1])
+            b = run_sum(bases[half * 150:], offs[half:] - offs[half], read_add=half)
+            assert ((a[0] + b[0]) % (1 << 64), a[1] ^ b[1], a[2] + b[2]) == base_sum, "4 M reads: splitting the batch changes the rows"
+            stl.close()
     finally:
         dx.close()
         hx.close()
