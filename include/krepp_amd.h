@@ -191,7 +191,12 @@ KR_API void kr_stream_destroy(kr_stream*);
                            /* (read_off/cnt/na, rec_key/sel/d); rec_v, rec_chisq, rec_hist and        */
                            /* read_onmers of the host view are then NULL / undefined, and the kernels */
                            /* do not write rec_v at all (NULL in a device view too) unless the batch  */
-                           /* filters (--filter) or taps                                              */
+                           /* filters (--filter) or taps.  The host view then holds the OUTPUT ROWS   */
+                           /* only -- the records report_distances prints (src/query.cpp:158-196),    */
+                           /* compacted on the device, 12 bytes a row across PCIe: nrecs == nrows,    */
+                           /* every rec_sel is 1, read_off / read_cnt are the reads' row ranges (a    */
+                           /* tiled batch still comes back as record slots with flags: same fields,   */
+                           /* same meaning, rec_sel 0 where a record is not a row)                    */
 
 /* Queue one batch: `bases` = concatenated ASCII sequences exactly as the FASTX
  * reader delivers them (QSeq::read_next_batch, src/rqseq.cpp:180-197),

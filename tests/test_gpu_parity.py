@@ -563,7 +563,16 @@ def test_lanes_do_not_change_results(capi, toy, toy_genomes, synth, monkeypatch)
         pb = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(nb,))
         st.submit(pb, offs, capi.KR_BASES_PINNED | capi.KR_ROWS_ONLY)
         r3 = st.collect()
-        assert sorted(zip(r3.rec_read.tolist(), r3.rec_key.tolist(), r3.rec_sel.tolist(), r3.rec_d.tolist())) == [t[:4] for t in key(one)]
+        # (rows-only batches leave the device as compact rows: the selected records and nothing else, every flag 1)
+        assert sorted(zip(r3.rec_read.tolist(), r3.rec_key.tolist(), r3.rec_sel.tolist(), r3.rec_d.tolist())) == [t[:4] for t in key(one) if t[2] == 1]
+        assert r3.nrows == len(r3.rec_key) == sum(t[2] for t in key(one)) and r3.rec_v is None
+        assert st.format_dist(hx, names) == text1
+        # ... and as record slots with flags when the compaction is switched off (KR_NO_ROW_COMPACTION: the path tiled batches take)
+        monkeypatch.setenv("KR_NO_ROW_COMPACTION", "1")
+        st.submit(pb, offs, capi.KR_BASES_PINNED | capi.KR_ROWS_ONLY)
+        r4 = st.collect()
+        monkeypatch.delenv("KR_NO_ROW_COMPACTION")
+        assert sorted(zip(r4.rec_read.tolist(), r4.rec_key.tolist(), r4.rec_sel.tolist(), r4.rec_d.tolist())) == [t[:4] for t in key(one)]
         assert st.format_dist(hx, names) == text1
         # device view: offsets index the stream's arrays (lane slices)
         monkeypatch.setenv("KR_LANES_DEVICE", "1")
