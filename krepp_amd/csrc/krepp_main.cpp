@@ -23,6 +23,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
 #include <vector>
@@ -250,7 +251,14 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
   kr_params_default(&pfront);
   pfront.hdist_th = p.hdist_th;
 
-  const uint32_t max_reads = getenv("KR_CLI_BATCH_READS") ? (uint32_t)std::max(1, atoi(getenv("KR_CLI_BATCH_READS"))) : (1u << 16);
+  // reads per batch: the kernels' efficiency grows with the batch (launch tails amortise, likelihood problems repeat): a million reads
+  // for `dist` on a large input, 65,536 for `place` / `seek` (more state per read) and for inputs of a few batches anyway
+  uint32_t max_reads_default = 1u << 16;
+  if (!place && !seek) {
+    struct stat sb;
+    if (stat(a.get("--query").c_str(), &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size >= (64ull << 20)) max_reads_default = 1u << 20;
+  }
+  const uint32_t max_reads = getenv("KR_CLI_BATCH_READS") ? (uint32_t)std::max(1, atoi(getenv("KR_CLI_BATCH_READS"))) : max_reads_default;
   const uint64_t batch_bases = (uint64_t)max_reads * 150, max_bases = batch_bases * 4;
   std::mutex mu;
   std::condition_variable cv_work, cv_done;

@@ -12,4 +12,17 @@ cd ../..
 cp krepp_amd/lib/libkrepp_amd.so /tmp/asan/orig.so
 trap 'cp /tmp/asan/orig.so krepp_amd/lib/libkrepp_amd.so' EXIT # whatever happens below, the product library comes back
 cp /tmp/asan/libkrepp_amd.so krepp_amd/lib/libkrepp_amd.so
-LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python -m pytest tests -m "not gpu" -x -q -p no:cacheprovider || true
+# the suite's exit code is this script's; the last lines of its output go to profiles/ (usage: scripts/asan_host.sh [summary file])
+SUMMARY=${1:-profiles/asan_host_latest.txt}
+set +e
+LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:abort_on_error=0 python -m pytest tests -m "not gpu" -x -q -p no:cacheprovider > /tmp/asan/pytest.log 2>&1
+RC=$?
+set -e
+{
+  echo "scripts/asan_host.sh: host C++ (kr_host.cpp, kr_build.cpp, kr_place.cpp) under -fsanitize=address, CPU test suite (pytest -m 'not gpu')"
+  echo "commit $(git rev-parse --short HEAD)$(git diff --quiet || echo ' + uncommitted changes'), $(date -u +%Y-%m-%dT%H:%MZ), exit code $RC"
+  echo "AddressSanitizer reports in the log: $(grep -c 'ERROR: AddressSanitizer' /tmp/asan/pytest.log || true)"
+  tail -5 /tmp/asan/pytest.log
+} > "$SUMMARY"
+cat "$SUMMARY"
+exit $RC

@@ -41,10 +41,21 @@ def test_bench_default_line_small():
     rl = out["roofline"]
     assert rl["bound"] == "hbm" and rl["unit"] == "GB/s" and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-9
     assert rl["traffic"] is None  # the committed PMC profile is of the 10 GB workload, not of this one
+    # a fraction of a physical peak: the dominant kernel's OWN bytes over its own time, and every stage's
+    assert 0 < rl["frac"] <= 1.0 and 0 < rl["step_frac"] <= 1.0
+    assert [k["stage"] for k in rl["kernels"]] == ["scan", "accumulate", "llh_select"]
+    for k in rl["kernels"]:
+        assert 0 <= k["frac"] <= 1.0 and k["avg_launch_ms"] > 0 and abs(k["frac"] - k["achieved_GBps"] / rl["peak"]) < 1e-9
+    assert rl["kernels"][0]["algorithmic_bytes_per_read"] == rl["algorithmic_bytes_per_read"] < rl["whole_path_algorithmic_bytes_per_read"]
+    # the rows that were checked are those of the last TIMED launch
+    ck = out["check"]
+    assert ck["from_timed_launch"] and ck["reads_in_that_launch"] == 200000 and ck["rows_equal"] and ck["max_rel_dist_err"] < 1e-6
+    assert ck["host_path_small_stream"]["rows_equal"]
+    assert out["config"]["item_list_placement"]["finished_before_timing"]
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["value"] > 0
     assert out["check"]["rows_equal"]
     hi = out["value_host_inclusive"]
-    assert hi["value"] > 0 and hi["streams"] == 3
+    assert hi["value"] > 0 and hi["streams"] == 3 and hi["steady_state"]["value"] > 0
 
 
 def test_bench_one_rank_rccl_replicates_the_index():
@@ -58,3 +69,17 @@ def test_bench_one_rank_rccl_replicates_the_index():
     assert bc["backend"] == "nccl" and bc["world"] == 1 and bc["bytes"] == out["config"]["index_device_bytes"] > 1e6
     assert bc["seconds"] > 0 and bc["GB_per_s"] > 0
     assert out["n_gpus"] == 1 and out["check"]["rows_equal"] and out["check"]["max_rel_dist_err"] < 1e-6
+
+
+def test_bench_two_ranks_on_the_10000_genome_index():
+    """BASELINE.json configs[3]'s code path walked on the one GPU at hand: `--workload syn10000` (10,000 genomes on a Yule tree,
+    seed 3, the generator of the 8-GPU configuration) with a reduced table (1 GB instead of 10), two ranks sharing the device over
+    gloo: rank 0 builds, inflates and uploads the index, every flat buffer is broadcast to rank 1 (kr_index_export ->
+    kr_index_import), the ranks run their own read shards, rank 0 checks the rows of its last timed launch against the oracle.
+    (The driver's SCALE run uses the same command with --backend nccl and one GPU per rank: BASELINE.md.)"""
+    out = run_bench("--gpus", "2", "--backend", "gloo", "--ranks-share-device", "--workload", "syn10000", "--index-gb", "1", "--reads-per-step", "200000",
+                    "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--check-reads", "2000", "--distinct-batches", "1")
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and "10000-genome" in out["config"]["workload"]
+    assert len(out["per_rank_reads_per_s"]) == 2 and min(out["per_rank_reads_per_s"]) > 0
+    assert out["index_broadcast"]["bytes"] == out["config"]["index_device_bytes"] > 1e9 and out["index_broadcast"]["world"] == 2
+    assert out["check"]["from_timed_launch"] and out["check"]["rows_equal"] and out["check"]["max_rel_dist_err"] < 1e-6

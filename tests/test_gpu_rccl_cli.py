@@ -42,3 +42,19 @@ def test_cli_dist_gpus_1_without_python(po, toy_index_dir, toy_reads):
     want = po.Index(toy_index_dir).dist(bases, offs, names, po.params(collect=4))["text"]
     body = r.stdout.split("\n", 2)[2]  # two header lines (src/krepp.cpp:311-319)
     assert body == want
+
+
+def test_cli_on_the_references_own_query_file(toy_index_dir):
+    """BASELINE.json configs[0]'s query file, test/query_toy.fq of the reference (committed as a fixture: data), through the
+    stand-alone CLI and the HIP path: its 100 reads come from real genomes and share nothing with the synthetic toy index, so
+    every read gets the no-hit row `SEQ_ID\tNA\tNaN` (src/query.cpp:173-176), under the two header lines (src/krepp.cpp:311-319)."""
+    exe = os.path.join(ROOT, "krepp_amd", "lib", "krepp")
+    fq = os.path.join(GOLDEN, "query_toy.fq")
+    ids = [l[1:].split()[0] for l in open(fq).read().splitlines()[0::4]]
+    assert len(ids) == 100
+    r = subprocess.run([exe, "dist", "-i", toy_index_dir, "-q", fq], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert lines[0].startswith("# software: krepp\tversion: ") and lines[1] == "SEQ_ID\tREFERENCE_NAME\tDIST"
+    assert lines[2:] == [f"{i}\tNA\tNaN" for i in ids]
+    assert "Total number of sequences queried: 100" in r.stderr
