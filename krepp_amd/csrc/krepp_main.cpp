@@ -251,12 +251,12 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
   kr_params_default(&pfront);
   pfront.hdist_th = p.hdist_th;
 
-  // reads per batch: the kernels' efficiency grows with the batch (launch tails amortise, likelihood problems repeat): a million reads
+  // reads per batch: the kernels' efficiency grows with the batch (launch tails amortise, likelihood problems repeat): 262,144 reads
   // for `dist` on a large input, 65,536 for `place` / `seek` (more state per read) and for inputs of a few batches anyway
   uint32_t max_reads_default = 1u << 16;
   if (!place && !seek) {
     struct stat sb;
-    if (stat(a.get("--query").c_str(), &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size >= (64ull << 20)) max_reads_default = 1u << 20;
+    if (stat(a.get("--query").c_str(), &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size >= (64ull << 20)) max_reads_default = 1u << 18;
   }
   const uint32_t max_reads = getenv("KR_CLI_BATCH_READS") ? (uint32_t)std::max(1, atoi(getenv("KR_CLI_BATCH_READS"))) : max_reads_default;
   const uint64_t batch_bases = (uint64_t)max_reads * 150, max_bases = batch_bases * 4;

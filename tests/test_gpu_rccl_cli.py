@@ -44,17 +44,33 @@ def test_cli_dist_gpus_1_without_python(po, toy_index_dir, toy_reads):
     assert body == want
 
 
-def test_cli_on_the_references_own_query_file(toy_index_dir):
+def test_cli_on_the_references_own_query_file(po, toy_index_dir, tmp_path, synth, capi):
     """BASELINE.json configs[0]'s query file, test/query_toy.fq of the reference (committed as a fixture: data), through the
-    stand-alone CLI and the HIP path: its 100 reads come from real genomes and share nothing with the synthetic toy index, so
-    every read gets the no-hit row `SEQ_ID\tNA\tNaN` (src/query.cpp:173-176), under the two header lines (src/krepp.cpp:311-319)."""
+    stand-alone CLI and the HIP path.  Its 100 reads come from real genomes and share nothing with a synthetic index: against an
+    index with the reference's toy parameters (-k 27 -w 35 -h 11, 25 synthetic references) every read gets the no-hit row
+    `SEQ_ID\tNA\tNaN` (src/query.cpp:173-176) under the two header lines (src/krepp.cpp:311-319); against the committed k = 21
+    index a few 21-mers match by chance, and the rows are the oracle's."""
+    from conftest import read_fastq_simple
+
     exe = os.path.join(ROOT, "krepp_amd", "lib", "krepp")
     fq = os.path.join(GOLDEN, "query_toy.fq")
-    ids = [l[1:].split()[0] for l in open(fq).read().splitlines()[0::4]]
+    names, bases, offs = read_fastq_simple(fq)
+    ids = [n.split()[0] for n in names]
     assert len(ids) == 100
-    r = subprocess.run([exe, "dist", "-i", toy_index_dir, "-q", fq], capture_output=True, text=True, timeout=600)
+    # (1) the toy parameters of the reference's README / configs[0]
+    nwk = os.path.join(GOLDEN, "tree_toy.nwk")
+    g = synth.evolve_genomes(open(nwk).read(), 100_000, seed=7)
+    tsv = synth.write_genomes(g, str(tmp_path / "g"))
+    idx = str(tmp_path / "idx")
+    capi.build_index(tsv, idx, nwk=nwk, k=27, w=35, h=11, m=4, r=1, frac=True, num_threads=4)
+    r = subprocess.run([exe, "dist", "-i", idx, "-q", fq], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = r.stdout.splitlines()
     assert lines[0].startswith("# software: krepp\tversion: ") and lines[1] == "SEQ_ID\tREFERENCE_NAME\tDIST"
     assert lines[2:] == [f"{i}\tNA\tNaN" for i in ids]
     assert "Total number of sequences queried: 100" in r.stderr
+    assert "\n".join(lines[2:]) + "\n" == po.Index(idx).dist(bases, offs, ids, po.params(collect=4))["text"]
+    # (2) the committed k = 21 index: whatever matches by chance, exactly as the oracle reports it
+    r = subprocess.run([exe, "dist", "-i", toy_index_dir, "-q", fq], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split("\n", 2)[2] == po.Index(toy_index_dir).dist(bases, offs, ids, po.params(collect=4))["text"]
