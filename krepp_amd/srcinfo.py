@@ -16,7 +16,19 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # everything kr_scan_kernel_t is compiled from (front end, probe list, slot scan, item stage) and nothing else
 SCAN_SOURCES = ("krepp_amd/csrc/kr_dev_scan.inc", "krepp_amd/csrc/kr_dev_scan_pipe.inc", "krepp_amd/csrc/kr_dev_common.inc", "krepp_amd/csrc/kr_devutil.h")
+# the kernels behind the other stages of a step (accumulate; de-duplication, likelihood, selection, row compaction): their traffic in
+# profiles/traffic_latest.json ("stages") is reported only while THESE are the sources that were profiled
+STAGE_SOURCES = ("krepp_amd/csrc/kr_dev_common.inc", "krepp_amd/csrc/kr_dev_expand.inc", "krepp_amd/csrc/kr_dev_accumulate.inc",
+                 "krepp_amd/csrc/kr_dev_likelihood.inc", "krepp_amd/csrc/kr_devutil.h")
 BUILD_INFO = os.path.join(ROOT, "krepp_amd", "lib", "build_info.json")
+
+
+def stage_src_sha() -> str:
+    h = hashlib.sha256()
+    for rel in STAGE_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def scan_src_sha() -> str:

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Per-kernel launch durations (kernel trace only) of an arbitrary python script: scripts/ktimes_cmd.sh <tag> <script.py> [args...]
+TAG=$1; shift
+export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=8
+OUT=gpurun_out/kt_$TAG
+rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 "$@" > $OUT/log.txt 2>&1
+python3 - <<PY
+import csv,glob,collections,re,statistics
+f=glob.glob("$OUT/**/*kernel_trace.csv",recursive=True)[0]
+d=collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    m=re.search(r'(kr_\w+)(<[^>]*>)?', r["Kernel_Name"])
+    if m: d[m.group(1)+(m.group(2) or "")].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6)
+for k,v in sorted(d.items(), key=lambda kv:-statistics.median(kv[1])):
+    print(f"{k:60s} n={len(v):3d} max={max(v):8.3f} ms  median={statistics.median(v):8.3f}")
+PY
+find $OUT -name "*.csv" -delete

@@ -42,12 +42,13 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     lines.append(f"\n== {sub}: per-dispatch counter averages ==")
     for k_, cs in acc.items():
-        if "kr_scan" not in k_ and "kr_acc" not in k_ and "llh" not in k_ and "select" not in k_:
+        if "kr_scan" not in k_ and "kr_acc" not in k_ and "llh" not in k_ and "select" not in k_ and "kr_dedup" not in k_ and "kr_rows" not in k_:
             continue
         for c, v in cs.items():
             lines.append(f"{k_[:90]}, {c}, n={len(v)}, avg={sum(v)/len(v):.6g}, max={max(v):.6g}")
-            summary.setdefault("pmc", {}).setdefault(k_[:60], {})[c] = sum(v) / len(v)
-            summary.setdefault("pmc_max", {}).setdefault(k_[:60], {})[c] = max(v)  # a full-size launch (the parity-check launch is small)
+            kk = k_.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:80]  # kernel name + template arguments
+            summary.setdefault("pmc", {}).setdefault(kk, {})[c] = sum(v) / len(v)
+            summary.setdefault("pmc_max", {}).setdefault(kk, {})[c] = max(v)  # a full-size launch (the parity-check launch is small)
 open(os.path.join(out, f"summary_{tag}.txt"), "w").write("\n".join(lines) + "\n")
 json.dump(summary, open(os.path.join(out, f"summary_{tag}.json"), "w"), indent=1)
 print("\n".join(lines))

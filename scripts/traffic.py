@@ -49,5 +49,23 @@ out = {
     "hbm_GBps_at_scan_ms": (lines * 128.0 + small * 64.0 + write_b) / (b["kernel_ms"]["scan"] * 1e-3) / 1e9,
     "method": __doc__.split("Method", 1)[1].strip(),
 }
+# ---- the other stages: every kernel's full-size launch (maximum over its dispatches), summed per stage.  Their reads are mostly
+# isolated gathers (colour ids, se_to_pse pairs, (d, v) of a problem): a request moves a 64-byte sector or a 128-byte line, the
+# counter does not say which, so both bounds are kept and the LOWER one (every request one sector) is what bench.py reports.
+stages = {"accumulate": ("kr_acc_kernel",), "llh_select": ("kr_dedup", "kr_llh", "kr_select", "kr_rows")}
+out["stages"] = {}
+for st_, pats in stages.items():
+    f_kb = w_kb = 0.0
+    names = []
+    for k_, c_ in summ["pmc_max"].items():
+        if any(p_ in k_ for p_ in pats) and "FETCH_SIZE" in c_ and "WRITE_SIZE" in c_:
+            f_kb += c_["FETCH_SIZE"]
+            w_kb += c_["WRITE_SIZE"]
+            names.append(k_)
+    out["stages"][st_] = {"kernels": names, "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb,
+                          "hbm_bytes_lower_bound_all_64B": (f_kb + w_kb) * 1024.0, "hbm_bytes_upper_bound_all_128B": (2 * f_kb + w_kb) * 1024.0,
+                          "hbm_bytes_per_launch": (f_kb + w_kb) * 1024.0, "ms": b["kernel_ms"]["accumulate" if st_ == "accumulate" else "llh_select"]}
+out["stage_src_sha"] = srcinfo.stage_src_sha()
+out["stage_sources"] = list(srcinfo.STAGE_SOURCES)
 json.dump(out, open(outf, "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("table", "hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "read_requests", "hbm_GBps_at_scan_ms")}))
