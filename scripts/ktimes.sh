@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8
 OUT=gpurun_out/kt_$TAG
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-inclusive --read-procs 1 --distinct-batches 1 "$@" > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-inclusive --read-procs 1 --distinct-batches 1 --skip-host-path-check "$@" > $OUT/bench.log 2>&1
 python3 - <<PY
 import csv,glob,collections,re,statistics
 f=glob.glob("$OUT/**/*kernel_trace.csv",recursive=True)[0]

@@ -6,7 +6,8 @@ export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8 # before the profiler's preload initialises the runtime
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-host-inclusive --read-procs 1 --distinct-batches 1 $@"
+# (--skip-host-path-check: every launch of the profiled kernels is a full-size one, so that the tool's averages are comparable with bench.py's)
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-host-inclusive --read-procs 1 --distinct-batches 1 --skip-host-path-check $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $ARGS > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py $ARGS > $OUT/bench_write.log 2>&1
