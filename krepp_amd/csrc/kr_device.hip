@@ -171,7 +171,7 @@ int kr_debug_front_end(const kr_index* ix, const uint8_t* bases, const uint64_t*
   HIP_TRY(hipMemset(d_valid, 0, n));
   HIP_TRY(hipMemset(d_pass, 0, n));
   BatchIn in{d_b, d_o, nreads};
-  const uint32_t planes = getenv("KR_DEBUG_FE_PLANES") && atoi(getenv("KR_DEBUG_FE_PLANES")) ? 1u : 0u; // tests: the bit-plane front end
+  const uint32_t planes = getenv("KR_DEBUG_FE_PLANES") ? (uint32_t)atoi(getenv("KR_DEBUG_FE_PLANES")) : 0u; // tests: 1 the bit-plane front end, 2 the byte-table one
   hipLaunchKernelGGL(kr_front_end_kernel, dim3(std::min(nreads, 4096u)), dim3(kWave), 0, 0, ix->dix, in, stride, d_rix, d_enc, d_valid, d_pass, planes);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(rix, d_rix, n * 4, hipMemcpyDeviceToHost));

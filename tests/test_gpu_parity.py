@@ -27,10 +27,11 @@ def gpu_dist(capi, dx, bases, offs, flags=0, **pkw):
     return st, res
 
 
-@pytest.mark.parametrize("planes", ["0", "1"], ids=["windows_pext", "bit_planes"])
+@pytest.mark.parametrize("planes", ["0", "1", "2"], ids=["windows_pext", "bit_planes", "byte_tables"])
 def test_front_end_bit_exact(capi, toy, toy_reads, monkeypatch, planes):
     """rix / enc32 / validity of every k-mer and strand (src/common.hpp:177-243, src/lshf.cpp:39-69) through both front ends: per-lane
-    windows + software PEXT, and the bit-plane form of the slotted scan kernels (kr_dev_common.inc: front_end_planes)."""
+    windows + software PEXT, the bit-plane form (kr_dev_common.inc: front_end_planes) and the byte tables in LDS that the slotted scan
+    kernel uses (front_end_tab)."""
     monkeypatch.setenv("KR_DEBUG_FE_PLANES", planes)
     hx, dx, ox = toy
     names, bases, offs = toy_reads
