@@ -277,3 +277,43 @@ def inflate_and_upload(torch, capi, hx, dev, local, index_gb, seed=20260101):
     del inc, cmer, pse, rho
     torch.cuda.empty_cache()
     return dx, host
+
+
+def inflate_in_child(index_dir, index_gb, device=0, seed=20260101, out_dir=None):
+    """The same inflation in a CHILD process (python -m krepp_amd.inflate_worker): it builds the table on the GPU with torch,
+    writes (inc, cmer) in the on-disk layout to `out_dir` (default: a directory in /dev/shm) and exits, so that the calling
+    process never allocates and frees tens of GB of device memory before it creates its streams -- device memory that has been
+    freed and is handed out again is slower to work in.
+    Returns (inc, cmer) as numpy arrays (memory-mapped files) and the directory (the caller removes it)."""
+    import subprocess
+    import sys
+    import tempfile
+
+    out_dir = out_dir or tempfile.mkdtemp(prefix="krepp_inflate_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "krepp_amd.inflate_worker", index_dir, str(index_gb), str(device), str(seed), out_dir],
+                       cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("krepp_amd.inflate_worker failed:\n" + r.stdout[-3000:])
+    inc = np.load(os.path.join(out_dir, "inc.npy"), mmap_mode="r")
+    cmer = np.load(os.path.join(out_dir, "cmer.npy"), mmap_mode="r")
+    return inc, cmer, out_dir
+
+
+def upload_with_table(capi, hx, local, inc, cmer):
+    """kr_index_upload of the host index `hx` with its library 0's table replaced by (inc, cmer) in HOST memory (on-disk layout)."""
+    import ctypes as C
+
+    inc = np.ascontiguousarray(inc, dtype=np.uint64)
+    cmer = np.ascontiguousarray(cmer, dtype=np.uint32)
+    lv = capi.KrLibView()
+    C.memmove(C.byref(lv), C.byref(hx.view.libs[0]), C.sizeof(lv))
+    lv.inc = C.cast(inc.ctypes.data, capi.u64p)
+    lv.cmer = C.cast(cmer.ctypes.data, capi.u32p)
+    lv.nkmers = cmer.size // 2
+    view = capi.KrIndexView()
+    C.memmove(C.byref(view), C.byref(hx.view), C.sizeof(view))
+    arr = (capi.KrLibView * 1)(lv)
+    view.libs = arr
+    dx = capi.DeviceIndex.from_view(view, local, capi.KR_VIEW_HOST, keep=(hx, inc, cmer, arr))
+    return dx
