@@ -10,16 +10,26 @@ from collections import defaultdict
 out, tag = sys.argv[1], sys.argv[2]
 
 
+def find_all(sub, pat):
+    """every file of a pass: the profiler writes one set per PROCESS, and bench.py has a child (krepp_amd.inflate_worker)"""
+    return sorted(glob.glob(os.path.join(out, sub, "**", pat), recursive=True))
+
+
 def find(sub, pat):
-    r = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
+    r = find_all(sub, pat)
     return r[0] if r else None
+
+
+def rows_of(sub, pat):
+    for f in find_all(sub, pat):
+        yield from csv.DictReader(open(f))
 
 
 summary = {"tag": tag}
 lines = []
 st = find("trace", "*kernel_stats.csv")
 if st:
-    rows = list(csv.DictReader(open(st)))
+    rows = [r for r in rows_of("trace", "*kernel_stats.csv")]
     lines.append("== rocprofv3 --kernel-trace --stats (kernel_stats.csv) ==")
     lines.append(",".join(rows[0].keys()) if rows else "")
     for r in rows:
@@ -28,7 +38,7 @@ if st:
 kt = find("trace", "*kernel_trace.csv")
 if kt:
     d = defaultdict(list)
-    for r in csv.DictReader(open(kt)):
+    for r in rows_of("trace", "*kernel_trace.csv"):
         d[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     lines.append("\n== per-kernel durations from kernel_trace.csv (ms): name, calls, avg, min, max ==")
     for k_, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
@@ -38,7 +48,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
     if not f:
         continue
     acc = defaultdict(lambda: defaultdict(list))
-    for r in csv.DictReader(open(f)):
+    for r in rows_of(sub, "*counter_collection.csv"):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     lines.append(f"\n== {sub}: per-dispatch counter averages ==")
     for k_, cs in acc.items():
