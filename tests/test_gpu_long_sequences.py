@@ -127,6 +127,28 @@ def test_a_tiled_batch_that_overflows_is_run_again_untiled(capi, po, toy, toy_ge
     assert_rows_close(st.collect().rows(), rows_of_oracle(ref))
 
 
+def test_max_records_bounds_a_tiled_batch_by_what_survives(capi, po, toy, toy_genomes):
+    """a batch that produces more records than the stream's max_records fails with KR_ERR_CAPACITY.  For a tiled batch
+    the count is of the records that SURVIVE -- the sequences' merged records and the ordinary reads' -- not of the tiles' own records,
+    which become holes (kr_tile_merge_kernel counts them): with room for the survivors the batch succeeds, with less it fails."""
+    hx, dx, ox = toy
+    bases, offs, names = make_batch(toy_genomes, 5)
+    nrec = len(ox.dist(bases, offs, names, po.params(collect=1))["accs"])  # every (read, strand, leaf) accumulator
+    ref = ox.dist(bases, offs, names, po.params(collect=7))
+    surviving = int((ref["accs"]["passed"] == 1).sum())
+    assert surviving > 40
+    st = dx.stream(max_reads=4096, max_bases=len(bases) + 64, max_records=surviving + 8)
+    st.submit(bases, offs)
+    assert_rows_close(st.collect().rows(), rows_of_oracle(ref))
+    st.close()
+    st = dx.stream(max_reads=4096, max_bases=len(bases) + 64, max_records=surviving // 2)
+    st.submit(bases, offs)
+    with pytest.raises(capi.KrError) as e:
+        st.collect()
+    assert e.value.code == capi.KR_ERR_CAPACITY
+    st.close()
+
+
 def test_a_stream_with_room_for_some_of_the_tiles_tiles_what_fits(capi, po, toy, toy_genomes):
     """A long sequence of nt tiles takes nt - 1 reads more than the batch has; a stream created for fewer reads than the tiles of
     all the batch's sequences tiles those that fit (in order) and leaves the others to one wave each: same results."""
