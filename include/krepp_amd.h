@@ -347,6 +347,9 @@ typedef struct kr_fastx_batch {
 KR_API int kr_fastx_open(const char* path, kr_fastx** out);
 KR_API int kr_fastx_next(kr_fastx*, uint64_t min_bases, kr_fastx_batch* out);
 KR_API uint64_t kr_fastx_parallel_chunks(const kr_fastx*); /* chunks taken from the thread pool so far */
+/* ordinary gzip input (csrc/kr_pgz.inc): chunks handed out with their records parsed by the pool / chunks whose speculative start
+ * the verified stream did not pass through (their range was inflated by the reader) / gaps closed by the reader */
+KR_API void kr_fastx_pgz_stats(const kr_fastx*, uint64_t* parsed, uint64_t* discarded, uint64_t* gaps);
 KR_API void kr_fastx_close(kr_fastx*);
 
 /* report_distances text (src/query.cpp:158-196; DISTANCE_FIELDS src/query.hpp:210;

@@ -90,7 +90,7 @@ EXPORTS = [
     "kr_debug_front_end", "kr_debug_stream_move", "kr_debug_stream_addrs", "kr_debug_item_placement", "kr_debug_brent", "kr_debug_colour_classes", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
     "kr_place_tree_create", "kr_place_tree_create_lineage", "kr_place_tree_nnodes", "kr_place_summary_add",
     "kr_place_summary_text", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_stream", "kr_place_frame", "kr_place_counters",
-    "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_format_dist", "kr_free", "kr_host_alloc", "kr_host_free",
+    "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_fastx_pgz_stats", "kr_format_dist", "kr_free", "kr_host_alloc", "kr_host_free",
     "kr_build_index", "kr_minimizers_cpu", "kr_minimizers_device", "kr_minimizers_free", "kr_last_error", "kr_version",
 ]
 
@@ -555,6 +555,11 @@ def read_fastx(path, min_bases=76800, stats=None):
     finally:
         if stats is not None:
             stats["parallel_chunks"] = int(lib.kr_fastx_parallel_chunks(h))
+            a, b_, c_ = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+            lib.kr_fastx_pgz_stats.restype = None
+            lib.kr_fastx_pgz_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+            lib.kr_fastx_pgz_stats(h, C.byref(a), C.byref(b_), C.byref(c_))
+            stats["gzip_chunks"] = {"parsed": int(a.value), "discarded": int(b_.value), "gaps": int(c_.value)}
         lib.kr_fastx_close(h)
     bases = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
     offsets = np.zeros(len(lens) + 1, np.uint64)

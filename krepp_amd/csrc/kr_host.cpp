@@ -33,6 +33,8 @@
 #include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
+#include <chrono>
+#include <sys/mman.h>
 #include <zlib.h>
 
 namespace kr {
@@ -1135,10 +1137,13 @@ struct BgzfSource {
   }
 };
 
+#include "kr_pgz.inc"
+
 struct kr_fastx {
   gzFile f = nullptr;
   std::unique_ptr<BgzfSource> bgzf; // block-gzipped input: members inflated in parallel
-  bool bgzf_error = false;
+  std::unique_ptr<pgz::Source> pgz; // ordinary gzip input: chunks of the one deflate stream inflated in parallel (kr_pgz.inc)
+  bool bgzf_error = false, pgz_error = false;
   std::string path;
   std::unique_ptr<FqPool> pool; // plain files: chunks parsed in parallel while this is set
   uint64_t pool_chunks = 0;     // chunks accepted from the pool
@@ -1177,17 +1182,30 @@ struct kr_fastx {
     return true;
   }
 
+  // gzread has stopped: at the end of the data, or because the stream is damaged / cut short (kseq would end the input silently
+  // there, src/kseq.h:92-101; a query file that lost its tail is reported instead, like a damaged block-gzipped one)
+  void note_zlib_error()
+  {
+    if (pgz || bgzf || !f) return;
+    int en = Z_OK;
+    (void)gzerror(f, &en);
+    if (en != Z_OK && en != Z_STREAM_END) pgz_error = true;
+  }
+
   int getc()
   {
     if (pos >= end) {
       if (eof) return -1;
-      int n = bgzf ? bgzf->read(buf.data(), (unsigned)buf.size()) : gzread(f, buf.data(), (unsigned)buf.size());
+      int n = pgz ? pgz->read(buf.data(), (unsigned)buf.size())
+                  : (bgzf ? bgzf->read(buf.data(), (unsigned)buf.size()) : gzread(f, buf.data(), (unsigned)buf.size()));
+      if (pgz && n < 0) pgz_error = true;
       if (bgzf && n == -2) {
         if (leave_bgzf()) n = gzread(f, buf.data(), (unsigned)buf.size());
         else n = -1, bgzf_error = true;
       }
       if (bgzf && n < 0) bgzf_error = true;
       if (n <= 0) {
+        note_zlib_error();
         eof = true;
         return -1;
       }
@@ -1207,13 +1225,16 @@ struct kr_fastx {
       pos = 0;
     }
     while (end < buf.size()) {
-      int n = bgzf ? bgzf->read(buf.data() + end, (unsigned)(buf.size() - end)) : gzread(f, buf.data() + end, (unsigned)(buf.size() - end));
+      int n = pgz ? pgz->read(buf.data() + end, (unsigned)(buf.size() - end))
+                  : (bgzf ? bgzf->read(buf.data() + end, (unsigned)(buf.size() - end)) : gzread(f, buf.data() + end, (unsigned)(buf.size() - end)));
+      if (pgz && n < 0) pgz_error = true;
       if (bgzf && n == -2) {
         if (leave_bgzf()) n = gzread(f, buf.data() + end, (unsigned)(buf.size() - end));
         else n = -1, bgzf_error = true;
       }
       if (bgzf && n < 0) bgzf_error = true;
       if (n <= 0) {
+        note_zlib_error();
         eof = true;
         break;
       }
@@ -1323,6 +1344,19 @@ int kr_fastx_open(const char* path, kr_fastx** out)
       r->bgzf->size = (uint64_t)sb.st_size;
       r->bgzf->depth = 2 * nt;
       for (unsigned t = 0; t < nt; ++t) r->bgzf->threads.emplace_back([p = r->bgzf.get()] { p->work(); });
+    } else if (fd >= 0 && pgz::Source::eligible(fd, (uint64_t)sb.st_size) && !(getenv("KR_PGZ") && atoi(getenv("KR_PGZ")) == 0)) {
+      // ordinary gzip: the deflate stream cut into chunks that are inflated in parallel (kr_pgz.inc; KR_PGZ=0: zlib's gzread alone)
+      r->pgz.reset(new pgz::Source());
+      r->pgz->fd = fd;
+      r->pgz->size = (uint64_t)sb.st_size;
+      r->pgz->depth = 2 * nt;
+      if (const char* ec = getenv("KR_PGZ_CHUNK")) r->pgz->chunk_bytes = std::max<uint64_t>(65536, strtoull(ec, nullptr, 10));
+      if (!r->pgz->open_map()) {
+        r->pgz->shutdown(); // (closes fd)
+        r->pgz.reset();
+      } else {
+        for (unsigned t = 0; t < nt; ++t) r->pgz->threads.emplace_back([p = r->pgz.get()] { p->work(); });
+      }
     } else if (fd >= 0 && pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
       r->pool.reset(new FqPool());
       r->pool->fd = fd;
@@ -1376,9 +1410,20 @@ int kr_fastx_next(kr_fastx* r, uint64_t min_bases, kr_fastx_batch* out)
     }
     if (!r->name_off.empty()) bpc = std::max<uint64_t>(bpc, min_bases); // a batch is ready: hand it over as it is
   }
+  if (r->pgz && r->pgz->parsed_mode) { // ordinary gzip, clean four-line FASTQ so far: the chunks come with their records parsed
+    pgz::Records rec;
+    rec.bases.swap(r->bases), rec.offsets.swap(r->offsets), rec.name_blob.swap(r->name_blob), rec.name_off.swap(r->name_off);
+    while (bpc < min_bases) {
+      const int st = r->pgz->next_records(rec);
+      if (st < 0) r->pgz_error = true, r->done = true;
+      if (st <= 0) break; // 0: the sequential parser continues below, on the bytes that follow
+      bpc = rec.bases.size();
+    }
+    rec.bases.swap(r->bases), rec.offsets.swap(r->offsets), rec.name_blob.swap(r->name_blob), rec.name_off.swap(r->name_off);
+  }
   std::string name;
   bool cont = false;
-  while (!r->pool && !r->done && bpc < min_bases) {
+  while (!r->pool && !(r->pgz && r->pgz->parsed_mode) && !r->done && bpc < min_bases) {
     long l = r->next_record(name, r->bases);
     cont = l >= 0;
     if (!cont) {
@@ -1392,6 +1437,7 @@ int kr_fastx_next(kr_fastx* r, uint64_t min_bases, kr_fastx_batch* out)
     r->name_blob.push_back('\0');
   }
   if (r->bgzf_error) return kr::fail(KR_ERR_IO, "damaged block-gzipped file (a member does not inflate or fails its CRC): " + r->path);
+  if (r->pgz_error) return kr::fail(KR_ERR_IO, "damaged gzip file (the stream does not inflate, or a member fails its CRC / length check): " + r->path);
   r->name_ptrs.resize(r->name_off.size());
   for (size_t i = 0; i < r->name_off.size(); ++i) r->name_ptrs[i] = r->name_blob.c_str() + r->name_off[i];
   out->bases = r->bases.data();
@@ -1402,13 +1448,21 @@ int kr_fastx_next(kr_fastx* r, uint64_t min_bases, kr_fastx_batch* out)
   return KR_OK;
 }
 
-uint64_t kr_fastx_parallel_chunks(const kr_fastx* r) { return r ? r->pool_chunks : 0; }
+uint64_t kr_fastx_parallel_chunks(const kr_fastx* r) { return r ? (r->pgz ? r->pgz->chunks_used : r->pool_chunks) : 0; }
+// (tests) ordinary gzip input: chunks whose speculative start was used / thrown away, gaps inflated sequentially
+void kr_fastx_pgz_stats(const kr_fastx* r, uint64_t* used, uint64_t* discarded, uint64_t* gaps)
+{
+  if (used) *used = r && r->pgz ? r->pgz->chunks_parsed : 0;
+  if (discarded) *discarded = r && r->pgz ? r->pgz->chunks_discarded : 0;
+  if (gaps) *gaps = r && r->pgz ? r->pgz->gaps : 0;
+}
 
 void kr_fastx_close(kr_fastx* r)
 {
   if (!r) return;
   if (r->pool) r->pool->shutdown();
   if (r->bgzf) r->bgzf->shutdown();
+  if (r->pgz) r->pgz->shutdown();
   if (r->f) gzclose(r->f);
   delete r;
 }
