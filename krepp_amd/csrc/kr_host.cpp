@@ -939,6 +939,8 @@ struct FqPool {
 };
 } // namespace
 
+#include "kr_pgz.inc"
+
 // ---- block-gzipped input (BGZF: a gzip file made of independent members of <= 64 KB, each announcing its
 // compressed size in a "BC" extra field and its inflated size in its trailer) ------------------------------------
 // Ordinary gzip is one dependent stream and is inflated by one thread (zlib, below).  BGZF members are independent:
@@ -960,7 +962,10 @@ struct BgzfSource {
     uint64_t off = 0, bytes = 0; // compressed range
     Buf in, out;
     bool ok = false, ready = false;
+    pgz::Records rec; // the records inside the run: out[h .. t) (kr_pgz.inc: find_records)
+    size_t h = 0, t = 0;
   };
+  pgz::Stitch st; // runs are handed out with their records (next_records) while st.parsed_mode; then as bytes (read)
   std::vector<std::unique_ptr<Run>> spare;
   int fd = -1;
   uint64_t size = 0, next_off = 0;
@@ -1031,6 +1036,8 @@ struct BgzfSource {
       if (rc != Z_STREAM_END || zs.avail_out != 0) return;
       if (crc32(crc32(0L, Z_NULL, 0), outp + m[2], isize) != crc) return;
     }
+    if (st.parsed_mode) pgz::find_records(outp, (size_t)total, r.off == 0, r.rec, r.h, r.t); // (the reader may clear the flag meanwhile: either is fine)
+    else r.rec.clear(), r.h = r.t = (size_t)total;
     r.ok = true;
   }
   void work()
@@ -1091,36 +1098,60 @@ struct BgzfSource {
       cv_todo.notify_one();
     }
   }
+  // the next run into `cur`: 1, or what read() returns when there is none (0 at the end, -1 on a damaged file, -2: continue with zlib at next_off)
+  int next_run()
+  {
+    if (cur) spare.push_back(std::move(cur)); // only this thread touches `spare`
+    cur.reset();
+    issue();
+    if (inflight.empty()) {
+      if (failed || trunc_at == next_off) return -1;
+      return next_off < size ? -2 : 0;
+    }
+    cur = std::move(inflight.front());
+    inflight.pop_front();
+    cur_pos = 0;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_ready.wait(lk, [&] { return cur->ready; });
+    }
+    if (!cur->ok) {
+      failed = true;
+      cur.reset();
+      return -1;
+    }
+    issue();
+    return 1;
+  }
+  // Records mode: the next run's records appended to `dst`.  1: done, 0: no more records this way (the end of the block-gzipped
+  // part, or bytes that are not clean four-line FASTQ: read() continues), -1: damaged file.
+  int next_records(pgz::Records& dst)
+  {
+    if (!st.parsed_mode) return 0;
+    const int k = next_run();
+    if (k == -1) return -1;
+    if (k != 1) { // (read() reports the same 0 / -2 again, behind the bytes the stitcher still holds)
+      st.end_of_records();
+      return 0;
+    }
+    const int rc = st.take(dst, cur->out.p.get(), cur->out.len, cur->h, cur->t, cur->rec);
+    cur_pos = cur->out.len; // taken, as records or into the stitcher's byte queue
+    return rc;
+  }
   // like gzread: up to n bytes, 0 at the end, -1 on a damaged file
   int read(unsigned char* dst, unsigned n)
   {
+    if (st.parsed_mode) st.end_of_records();
     for (;;) {
+      if (const unsigned k = st.drain(dst, n)) return (int)k;
       if (cur && cur_pos < cur->out.len) {
         const unsigned k = (unsigned)std::min<size_t>(n, cur->out.len - cur_pos);
         memcpy(dst, cur->out.p.get() + cur_pos, k);
         cur_pos += k;
         return (int)k;
       }
-      if (cur) spare.push_back(std::move(cur)); // only this thread touches `spare`
-      cur.reset();
-      issue();
-      if (inflight.empty()) { // -2: continue with zlib at next_off
-        if (failed || trunc_at == next_off) return -1;
-        return next_off < size ? -2 : 0;
-      }
-      cur = std::move(inflight.front());
-      inflight.pop_front();
-      cur_pos = 0;
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv_ready.wait(lk, [&] { return cur->ready; });
-      }
-      if (!cur->ok) {
-        failed = true;
-        cur.reset();
-        return -1;
-      }
-      issue();
+      const int k = next_run();
+      if (k != 1) return k;
     }
   }
   void shutdown()
@@ -1137,8 +1168,6 @@ struct BgzfSource {
   }
 };
 
-#include "kr_pgz.inc"
-
 struct kr_fastx {
   gzFile f = nullptr;
   std::unique_ptr<BgzfSource> bgzf; // block-gzipped input: members inflated in parallel
@@ -1147,6 +1176,7 @@ struct kr_fastx {
   std::string path;
   std::unique_ptr<FqPool> pool; // plain files: chunks parsed in parallel while this is set
   uint64_t pool_chunks = 0;     // chunks accepted from the pool
+  uint64_t bgzf_parsed = 0;     // (block-gzipped runs handed out with their records, once `bgzf` is gone)
   std::vector<unsigned char> buf;
   size_t pos = 0, end = 0;
   bool eof = false;
@@ -1159,11 +1189,14 @@ struct kr_fastx {
   std::vector<size_t> name_off;
   std::vector<const char*> name_ptrs;
 
+  bool records_mode() const { return (pgz && pgz->st.parsed_mode) || (bgzf && bgzf->st.parsed_mode); }
+
   // the block-gzipped part of the file has ended before the file has: what follows (an ordinary gzip member
   // appended with `cat`, say) is zlib's, from that offset on
   bool leave_bgzf()
   {
     const uint64_t off = bgzf->next_off;
+    bgzf_parsed = bgzf->st.chunks_parsed;
     bgzf->shutdown();
     bgzf.reset();
     int fd = open(path.c_str(), O_RDONLY);
@@ -1410,12 +1443,12 @@ int kr_fastx_next(kr_fastx* r, uint64_t min_bases, kr_fastx_batch* out)
     }
     if (!r->name_off.empty()) bpc = std::max<uint64_t>(bpc, min_bases); // a batch is ready: hand it over as it is
   }
-  if (r->pgz && r->pgz->parsed_mode) { // ordinary gzip, clean four-line FASTQ so far: the chunks come with their records parsed
+  if (r->records_mode()) { // gzip input, clean four-line FASTQ so far: the chunks come with their records parsed by the pool
     pgz::Records rec;
     rec.bases.swap(r->bases), rec.offsets.swap(r->offsets), rec.name_blob.swap(r->name_blob), rec.name_off.swap(r->name_off);
     while (bpc < min_bases) {
-      const int st = r->pgz->next_records(rec);
-      if (st < 0) r->pgz_error = true, r->done = true;
+      const int st = r->pgz ? r->pgz->next_records(rec) : r->bgzf->next_records(rec);
+      if (st < 0) (r->pgz ? r->pgz_error : r->bgzf_error) = true, r->done = true;
       if (st <= 0) break; // 0: the sequential parser continues below, on the bytes that follow
       bpc = rec.bases.size();
     }
@@ -1423,7 +1456,7 @@ int kr_fastx_next(kr_fastx* r, uint64_t min_bases, kr_fastx_batch* out)
   }
   std::string name;
   bool cont = false;
-  while (!r->pool && !(r->pgz && r->pgz->parsed_mode) && !r->done && bpc < min_bases) {
+  while (!r->pool && !r->records_mode() && !r->done && bpc < min_bases) {
     long l = r->next_record(name, r->bases);
     cont = l >= 0;
     if (!cont) {
@@ -1452,7 +1485,7 @@ uint64_t kr_fastx_parallel_chunks(const kr_fastx* r) { return r ? (r->pgz ? r->p
 // (tests) ordinary gzip input: chunks whose speculative start was used / thrown away, gaps inflated sequentially
 void kr_fastx_pgz_stats(const kr_fastx* r, uint64_t* used, uint64_t* discarded, uint64_t* gaps)
 {
-  if (used) *used = r && r->pgz ? r->pgz->chunks_parsed : 0;
+  if (used) *used = !r ? 0 : r->pgz ? r->pgz->st.chunks_parsed : r->bgzf ? r->bgzf->st.chunks_parsed : r->bgzf_parsed;
   if (discarded) *discarded = r && r->pgz ? r->pgz->chunks_discarded : 0;
   if (gaps) *gaps = r && r->pgz ? r->pgz->gaps : 0;
 }

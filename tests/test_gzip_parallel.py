@@ -199,3 +199,23 @@ def test_decoder_against_zlib_on_random_streams(capi, tmp_path, par_env):
         got = capi.read_fastx(str(gz), min_bases=100000, stats=st)
         assert _same(got, want), (trial, st)
         assert st["gzip_chunks"]["parsed"] >= 1 or len(data) < 200000, (trial, st)
+
+
+def test_block_gzipped_runs_come_with_their_records(capi, tmp_path, par_env):
+    """BGZF: the threads that inflate a run of members (~1 MB of the file) parse its records too; the bytes between the runs'
+    records go through the same exact-seam check as ordinary gzip chunks."""
+    from test_host import _bgzf_bytes
+    recs = _fastq(24000, seed=5)
+    tail = b">f1 x\nACGTACGT\nACGT\n"
+    for key, data in (("clean", b"".join(recs)), ("fasta_tail", b"".join(recs) + tail), ("no_final_newline", b"".join(recs)[:-1])):
+        plain, bg = tmp_path / (key + ".fq"), tmp_path / (key + ".fq.gz")
+        plain.write_bytes(data)
+        bg.write_bytes(_bgzf_bytes(data, block=50000, level=0))  # stored members: ~3.6 MB of file = four runs
+        par_env["KR_FASTX_THREADS"] = "0"
+        want = capi.read_fastx(str(plain), min_bases=100000)
+        for threads in ("3", "1"):
+            par_env["KR_FASTX_THREADS"] = threads
+            st = {}
+            got = capi.read_fastx(str(bg), min_bases=100000, stats=st)
+            assert _same(got, want), (key, threads, st)
+            assert st["gzip_chunks"]["parsed"] >= 3, (key, st)

@@ -217,8 +217,10 @@ def test_block_gzipped_input_is_inflated_in_parallel(capi, tmp_path):
         want = capi.read_fastx(str(plain), min_bases=50000)
         for threads in ("3", "1"):
             os.environ["KR_FASTX_THREADS"] = threads
-            got = capi.read_fastx(str(bg), min_bases=50000)
+            st = {}
+            got = capi.read_fastx(str(bg), min_bases=50000, stats=st)
             assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+            assert st["gzip_chunks"]["parsed"] >= 1, st  # the threads that inflate a run of members parse its records too (kr_pgz.inc: Stitch)
         os.environ["KR_FASTX_THREADS"] = "0"  # zlib stream reader on the same file
         got = capi.read_fastx(str(bg), min_bases=50000)
         assert got[0] == want[0] and np.array_equal(got[1], want[1])
