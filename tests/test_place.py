@@ -357,12 +357,16 @@ def test_cli_dist_on_a_file_large_enough_for_the_parallel_reader(po, toy_index_d
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("limits", ["3,8", "1,1", "6,1024"])
+@pytest.mark.parametrize("limits", ["3,8", "1,1", "6,1024", "3,8/global"])
 def test_heavy_reads_stay_on_the_device(capi, po, toy_index_dir, toy_reads, toy_genomes, synth, monkeypatch, limits):
     """Reads with more leaves / distinct ancestors than kr_place_kernel's LDS arrays hold (256 / 1024; lowered here so
-    that the 25-leaf tree has such reads) are done by the kernel's second launch with its arrays in global scratch:
+    that the 25-leaf tree has such reads) are done by the kernel's second launch, whose arrays hold the whole tree -- in its
+    dynamic LDS where the tree is small enough, in global scratch otherwise ("/global": forced here):
     no batch goes to the host back end, and text, placements and summary equal the host back end's bit for bit and
     the oracle's (src/query.cpp:248-281, Minfo::add src/query.hpp:139-152)."""
+    if limits.endswith("/global"):
+        limits = limits.split("/")[0]
+        monkeypatch.setenv("KR_PLACE_HEAVY_GLOBAL", "1")
     names, bases, offs = toy_reads
     b2, o2, n2 = synth.sample_reads(toy_genomes, 5000, seed=29)
     hx = capi.HostIndex(toy_index_dir)
