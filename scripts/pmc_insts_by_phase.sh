@@ -8,10 +8,10 @@ for v in ${SKIPS:-0 256 128 64 16 2}; do
   KR_DEBUG_SKIP=$v rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d gpurun_out/pmci_$v -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-inclusive --check-reads 1000 --reads-per-step 1000000 --read-procs 1 --distinct-batches 1 > gpurun_out/pmci_$v/log.txt 2>&1
   python3 - <<PY
 import csv,glob,collections
-f=glob.glob("gpurun_out/pmci_$v/**/*counter_collection.csv",recursive=True)[0]
 m=collections.defaultdict(float)
-for r in csv.DictReader(open(f)):
-    if "kr_acc_kernel_t<true, 5, false>" in r["Kernel_Name"]: m[r["Counter_Name"]]=max(m[r["Counter_Name"]], float(r["Counter_Value"]))
+for f in glob.glob("gpurun_out/pmci_$v/**/*counter_collection.csv",recursive=True):  # (one file per process: the index inflation runs in a child)
+    for r in csv.DictReader(open(f)):
+        if "kr_acc_kernel_t<true, 5, false, 7" in r["Kernel_Name"]: m[r["Counter_Name"]]=max(m[r["Counter_Name"]], float(r["Counter_Value"]))
 print("KR_DEBUG_SKIP=$v per read:", {k: round(x/1e6,1) for k,x in sorted(m.items())})
 PY
   find gpurun_out/pmci_$v -name "*.csv" -delete
