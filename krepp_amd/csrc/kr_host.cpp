@@ -821,6 +821,14 @@ struct FqChunk {
   bool ok = false;       // consumed [a, b) exactly
   uint64_t clean_end = 0; // file offset where the clean prefix ends
   bool ready = false;
+  // (chunks are recycled with their buffers: fresh multi-MB allocations per chunk cost more in page faults than the parse they hold)
+  std::unique_ptr<unsigned char[]> raw;
+  size_t raw_cap = 0;
+  void reset(uint64_t a_, uint64_t b_)
+  {
+    a = a_, b = b_, ok = ready = false, clean_end = 0;
+    bases.clear(), offsets.assign(1, 0), name_blob.clear(), name_off.clear();
+  }
 };
 
 struct FqPool {
@@ -829,6 +837,7 @@ struct FqPool {
   bool issued_all = false;
   size_t depth = 0;
   std::deque<std::unique_ptr<FqChunk>> inflight; // file order
+  std::vector<std::unique_ptr<FqChunk>> spare;   // handed out and taken back by the reader thread only
   std::deque<FqChunk*> todo;
   std::mutex mu;
   std::condition_variable cv_todo, cv_ready;
@@ -847,7 +856,8 @@ struct FqPool {
   void parse(FqChunk& c)
   {
     const size_t len = (size_t)(c.b - c.a);
-    std::unique_ptr<unsigned char[]> buf(new unsigned char[std::max<size_t>(1, len)]); // not zero-filled
+    if (len > c.raw_cap || !c.raw) c.raw.reset(new unsigned char[len + len / 8 + 64]), c.raw_cap = len + len / 8 + 64; // not zero-filled
+    std::unique_ptr<unsigned char[]>& buf = c.raw;
     size_t p = 0;
     if (pread_all(fd, buf.get(), c.a, len)) {
       c.bases.reserve(len / 2);
@@ -911,8 +921,10 @@ struct FqPool {
         issued_all = true;
         break;
       }
-      std::unique_ptr<FqChunk> c(new FqChunk());
-      c->a = next_off, c->b = b;
+      std::unique_ptr<FqChunk> c;
+      if (!spare.empty()) c = std::move(spare.back()), spare.pop_back();
+      else c.reset(new FqChunk());
+      c->reset(next_off, b);
       next_off = b;
       {
         std::lock_guard<std::mutex> lk(mu);
@@ -1433,7 +1445,11 @@ int kr_fastx_next(kr_fastx* r, uint64_t min_bases, kr_fastx_batch* out)
       r->name_off.swap(c->name_off);
       bpc = r->bases.size();
       if (!c->ok) fall_back = true, resume = c->clean_end;
-      else P.issue(), r->pool_chunks++;
+      else {
+        r->pool_chunks++;
+        if (P.spare.size() < 2 * P.depth) P.spare.push_back(std::move(c)); // (with the batch's previous vectors: their capacity serves the next chunk)
+        P.issue();
+      }
     }
     if (fall_back) { // the rest of the input goes through the sequential reader
       P.shutdown();
