@@ -36,13 +36,13 @@ for tab, label in ((1, "--tabular"), (2, "--summarize"), (0, "jplace")):
           f"heavy reads (upper bound, 3 runs) {capi.place_heavy_reads() - hv0}; text {len(text) / 1e6:.1f} MB")
     pl.close()
 
-# two host threads with a stream each (as the CLI's workers run; ctypes releases the GIL): one thread's last phase on the host while
-# the other's batch is on the device -- the throughput of kr_place_stream as a pipeline
+# NT host threads with a stream each (as the CLI's workers run; ctypes releases the GIL): one thread's last phase on the host while
+# another's batch is on the device -- the throughput of kr_place_stream as a pipeline
 import threading
-for tab, label in ((1, "--tabular"), (2, "--summarize")):
+for NT in (2, 3, 4):
+  for tab, label in ((1, "--tabular"), (2, "--summarize")):
     pl = capi.Placer(hx, None, 0, tabular=tab, max_reads=n, max_bases=len(b))
-    st2 = pl.dx.stream(params=pl.st.params, max_reads=n, max_bases=len(b), max_records=n * 128)
-    sts = [pl.st, st2]
+    sts = [pl.st] + [pl.dx.stream(params=pl.st.params, max_reads=n, max_bases=len(b), max_records=n * 128) for _ in range(NT - 1)]
     ob = (len(b) + 7) & ~7
     pin = pl.lib.kr_host_alloc(ob + 8 * len(o))
     C.memmove(pin, np.ascontiguousarray(b).ctypes.data, len(b))
@@ -50,25 +50,26 @@ for tab, label in ((1, "--tabular"), (2, "--summarize")):
     bb = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(len(b),))
     oo = np.ctypeslib.as_array(C.cast(pin + ob, C.POINTER(C.c_uint64)), shape=(len(o),))
     FL = capi.KR_TAP_ACCS | capi.KR_BASES_PINNED
-    prevs = [C.c_int(0), C.c_int(0)]
+    prevs = [C.c_int(0) for _ in range(NT)]
     def one(w):
         sts[w].submit(bb, oo, FL)
         txt, ln, pls, npl = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64()
         capi.check(pl.lib.kr_place_stream(hx.h, pl.dx.h, pl.pt, sts[w].h, n, oo.ctypes.data, arr, C.byref(pl.popts), tab, C.byref(prevs[w]),
                                           C.byref(txt), C.byref(ln), C.byref(pls) if tab == 2 else None, C.byref(npl) if tab == 2 else None))
         pl.lib.kr_free(txt), pl.lib.kr_free(pls)
-    for w in (0, 1):
+    for w in range(NT):
         one(w)  # warm-up: workspaces
-    nb = 12
+    per = 6
     def worker(w):
-        for _ in range(nb // 2):
+        for _ in range(per):
             one(w)
-    ths = [threading.Thread(target=worker, args=(w,)) for w in range(2)]
+    ths = [threading.Thread(target=worker, args=(w,)) for w in range(NT)]
     t = time.time()
     for th in ths: th.start()
     for th in ths: th.join()
     dtp = time.time() - t
-    print(f"{label}: two host threads with a stream each, C ABI only (submit + kr_place_stream): {nb} x {n} reads in {dtp:.3f} s = {nb * n / dtp / 1e6:.2f} M reads/s")
-    st2.close()
+    print(f"{label}: {NT} host threads with a stream each, C ABI only (submit + kr_place_stream): {NT * per} x {n} reads in {dtp:.3f} s = {NT * per * n / dtp / 1e6:.2f} M reads/s")
+    for st_ in sts[1:]:
+        st_.close()
     pl.lib.kr_host_free(pin)
     pl.close()
