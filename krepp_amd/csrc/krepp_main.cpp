@@ -377,10 +377,10 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
     }
     kr_stream_destroy(st);
   };
-  // two workers (each with its own stream) per GPU: one formats its rows while the other's batch is on the device.  `place`: three --
-  // its host phase (filter, LWR, text) is as long as its device leg since round 4 (14.2 M reads/s with two host
-  // threads on the 1000-genome tree, 18.6 M with three)
-  const int wpg = getenv("KR_CLI_WORKERS_PER_GPU") ? std::max(1, atoi(getenv("KR_CLI_WORKERS_PER_GPU"))) : (place ? 3 : 2);
+  // two workers (each with its own stream) per GPU: one formats its rows while the other's batch is on the device.  (`place` on a
+  // 1000-genome tree, 8 M reads, 65,536-read batches: 8.2 M reads/s with two workers, 7.6 M with three -- `scripts/time_cli_place_big.py`;
+  // with 400,000-read batches through the C ABI a third host thread does pay: DESIGN.md 3.4)
+  const int wpg = getenv("KR_CLI_WORKERS_PER_GPU") ? std::max(1, atoi(getenv("KR_CLI_WORKERS_PER_GPU"))) : 2;
   const int nworkers = ngpus * wpg;
   std::vector<std::thread> workers;
   for (int w = 0; w < nworkers; ++w) workers.emplace_back(worker, w % ngpus);
