@@ -1377,7 +1377,7 @@ int kr_fastx_open(const char* path, kr_fastx** out)
   {
     const char* et = getenv("KR_FASTX_THREADS");
     const char* em = getenv("KR_FASTX_PAR_MIN");
-    unsigned nt = et ? (unsigned)atoi(et) : std::min(12u, std::max(1u, kr::usable_cpus() / 2));
+    unsigned nt = et ? (unsigned)atoi(et) : std::min(12u, std::max(1u, kr::usable_cpus() * 3 / 4));
     const uint64_t par_min = em ? strtoull(em, nullptr, 10) : (32ull << 20);
     struct stat sb;
     const bool regular = nt && stat(path, &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size >= par_min; // never a pipe

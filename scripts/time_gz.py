@@ -80,7 +80,7 @@ for name, path in files.items():
         best = min(reader(path) for _ in range(2))
         for k, v in keep.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
-        print("%-8s %-28s %6.2f s  %6.2f M reads/s" % (name, env or "default (8 threads)", best, n / best / 1e6), flush=True)
+        print("%-8s %-28s %6.2f s  %6.2f M reads/s" % (name, env or "default (min(12, 3/4 of the usable CPUs))", best, n / best / 1e6), flush=True)
 
 print("== krepp dist end to end ==")
 exe = os.path.join(root, "krepp_amd", "lib", "krepp")
