@@ -4,6 +4,7 @@
 TAG=$1; shift
 export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8 # before the profiler's preload initialises the runtime
+export KR_ITEM_PLACEMENT_TRIALS=0 # (bench.py asks for placement trials during its set-up: under the profiler every launch runs on the one list, so that the tool's per-kernel averages are over like launches)
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 # (--skip-host-path-check: every launch of the profiled kernels is a full-size one, so that the tool's averages are comparable with bench.py's)
