@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1048,7 +1049,7 @@ struct BgzfSource {
       if (rc != Z_STREAM_END || zs.avail_out != 0) return;
       if (crc32(crc32(0L, Z_NULL, 0), outp + m[2], isize) != crc) return;
     }
-    if (st.parsed_mode) pgz::find_records(outp, (size_t)total, r.off == 0, r.rec, r.h, r.t); // (the reader may clear the flag meanwhile: either is fine)
+    if (st.parsed_mode.load(std::memory_order_relaxed)) pgz::find_records(outp, (size_t)total, r.off == 0, r.rec, r.h, r.t); // (the reader may clear the flag meanwhile: either is fine)
     else r.rec.clear(), r.h = r.t = (size_t)total;
     r.ok = true;
   }

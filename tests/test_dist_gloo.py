@@ -92,3 +92,18 @@ def test_bench_gpus_n_launches_n_rank_processes():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
                          env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=3" in bad.stderr
+
+
+def test_bench_gpus_8_launches_eight_rank_processes():
+    """The driver's 8-GPU command shape (`python bench.py --gpus 8`): eight rank processes, one rendezvous, eight contiguous
+    shards that cover the job (the GPU half of this rehearsal is tests/test_gpu_bench.py::test_bench_eight_ranks_share_one_gpu)."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["ranks"] == list(range(8)) and out["distinct_processes"] == 8
+    assert out["shards"][0][0] == 0 and all(out["shards"][i][1] == out["shards"][i + 1][0] for i in range(7))

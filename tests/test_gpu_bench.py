@@ -83,3 +83,21 @@ def test_bench_two_ranks_on_the_10000_genome_index():
     assert len(out["per_rank_reads_per_s"]) == 2 and min(out["per_rank_reads_per_s"]) > 0
     assert out["index_broadcast"]["bytes"] == out["config"]["index_device_bytes"] > 1e9 and out["index_broadcast"]["world"] == 2
     assert out["check"]["from_timed_launch"] and out["check"]["rows_equal"] and out["check"]["max_rel_dist_err"] < 1e-6
+
+
+def test_bench_eight_ranks_share_one_gpu():
+    """The 8-rank start of BASELINE.json configs[3] rehearsed on one box: eight rank processes (launch_ranks), each generating
+    its own read shard under the box's CPU quota while rank 0 builds the 10,000-genome index, ONE build + upload, SEVEN
+    kr_index_import + broadcast receptions (gloo carrying the device buffers; the driver's run is this command with
+    --backend nccl and a GPU per rank), eight read shards, MAX-over-ranks timing, and the rows of rank 0's last timed
+    launch equal to the oracle's (src/krepp.cpp:92-106 is the load loop, :360-387 the batch loop this replaces)."""
+    out = run_bench("--gpus", "8", "--backend", "gloo", "--ranks-share-device", "--workload", "syn10000", "--index-gb", "1",
+                    "--reads-per-step", "100000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host-inclusive",
+                    "--check-reads", "2000", "--distinct-batches", "1")
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and "10000-genome" in out["config"]["workload"]
+    assert len(out["per_rank_reads_per_s"]) == 8 and min(out["per_rank_reads_per_s"]) > 0
+    assert out["index_broadcast"]["world"] == 8 and out["index_broadcast"]["bytes"] == out["config"]["index_device_bytes"] > 1e9
+    assert out["check"]["from_timed_launch"] and out["check"]["rows_equal"] and out["check"]["max_rel_dist_err"] < 1e-6
+    assert out["value"] <= 8.05 * max(out["per_rank_reads_per_s"])
+    print(f"8 ranks on one GPU: setup_s {out['setup_s']:.1f}, broadcast {out['index_broadcast']['seconds']:.2f} s, "
+          f"{out['value'] / 1e6:.1f} M reads/s whole job")

@@ -2,13 +2,16 @@
 parameters -k 29 -w 35 -h 13, m4r1-frac: 2^25 rows) whose table is inflated to 10 GB resident in HBM — the
 exact index bench.py measures (krepp_amd.synth.inflate_and_upload, same seeds).
 
-Per table layout (FILTER slots, the default for this table: one 128-byte line of 24-bit codes per probe, candidates verified by
-the accumulate kernel; the slotted copy of the bucket heads with W = 64 words; and KR_SLOT_LOG2W=0, the packed table only): 20,000 reads against the oracle holding the same table (Index.replace_table) — table hits
-(src/query.cpp:352-368, src/index.cpp:160-168) and histograms (src/query.hpp:153-176) bit-exact, DIST within the
-north star's 1e-6 relative — then a full 1,000,000-read batch through the size-independent properties
-(reverse complement, permutation, split); on the default layout the same three properties once more at 4,000,000 reads per
-launch -- the size class of bench.py's timed launches (item lists of hundreds of millions of entries, every cursor range in use)
--- compared through an order-independent 128-bit checksum of the rows.
+Per table layout -- slot format 6, THE DEFAULT for this table and the one bench.py times (the slotted copy of the bucket
+heads, W = 64 words = two 128-byte lines per probe); slot format 9, opt-in (KR_SLOT_FILTER / KR_SLOT_LOG2W=9: FILTER slots, one
+128-byte line of 24-bit codes per probe, candidates verified by the accumulate kernel; kFilterByDefault = false in
+kr_host_index.inc); and KR_SLOT_LOG2W=0, the packed table only -- 20,000 reads against the oracle holding the same table
+(Index.replace_table) — table hits (src/query.cpp:352-368, src/index.cpp:160-168) and histograms (src/query.hpp:153-176)
+bit-exact, DIST within the north star's 1e-6 relative — then a full 1,000,000-read batch through the size-independent
+properties (reverse complement, permutation, split); on the default layout (and on the filter slots) the same three properties
+once more at 4,000,000 reads per launch -- the size class of bench.py's timed launches (item lists of hundreds of millions of
+entries, every cursor range in use; the byte-table front end, finalize_events_fast, kr_select_lane_kernel and the row compaction
+all on their default paths) -- compared through an order-independent 128-bit checksum of the rows.
 """
 import os
 
@@ -136,8 +139,9 @@ def test_syn1000_10gb_index_vs_oracle_and_full_batch_properties(capi, po, synth,
         monkeypatch.delenv("KR_LANES")
         monkeypatch.delenv("KR_ITEM_PLACEMENT_TRIALS", raising=False)
 
-        # ---- 4,000,000 reads per launch (default layout): the same properties at the size class of bench.py's timed launches ----
-        if slot_log2w == "9":
+        # ---- 4,000,000 reads per launch (format 6 = the default layout bench.py times; format 9 = the opt-in filter slots):
+        #      the same properties at the size class of bench.py's timed launches ----
+        if slot_log2w in ("6", "9"):
             n = N_LAUNCH
             bases, offs = make_reads(synth, genomes, n, seed=6)
             stl = dx.stream(max_reads=n, max_bases=len(bases), max_records=n * 64)
@@ -256,4 +260,40 @@ def test_place_on_the_1000_genome_tree_never_leaves_the_device(capi, synth, syn)
         print(f"heavy reads (upper bound): {heavy} of {n}")
     finally:
         placer.close()
+        hx.close()
+
+
+def test_place_on_the_1000_genome_tree_matches_the_oracle(capi, po, synth, syn):
+    """`krepp place` on the 1000-genome Yule tree against the ORACLE's restatement of IBatch::place_sequences /
+    report_placement (src/query.cpp:198-333; ancestors' fractional histograms, candidate rule, Brent on internal nodes,
+    chi-square against the closest leaf, LWR), not only against this repo's own host back end: 2,000 reads, jplace and
+    --tabular -- placements field by field (the north star's 1e-6 on the fp64 fields), the text byte for byte, and no batch
+    on the host back end.  Reads here reach dozens of leaves and hundreds of ancestors: the kernel's global-scratch launch
+    is live (the 25-leaf trees of tests/test_place.py never reach it)."""
+    idx, genomes = syn
+    n = 2000
+    bases, offs, names = synth.sample_reads(genomes, n, seed=4242)
+    hx = capi.HostIndex(idx)
+    ox = po.Index(idx)
+    ox.set_placement_tree(None)  # the index's own tree as backbone (TargetIndex::ensure_backbone, src/krepp.cpp:48-64)
+    dev0, host0 = capi.place_counters()
+    try:
+        for tabular in (False, True):
+            want = ox.place(bases, offs, names, po.params(no_filter=0, num_threads=min(16, os.cpu_count() or 1)), tabular=tabular)
+            placer = capi.Placer(hx, None, 0, tabular=tabular, max_reads=n, max_bases=len(bases))
+            text, pl = placer.place(bases, offs, names)
+            placer.close()
+            key = lambda p: sorted((int(r), int(e)) for r, e in zip(p["read"], p["edge"]))
+            assert len(pl) > n // 2 and len(np.unique(pl["read"])) > n // 2
+            assert key(pl) == key(want["placements"]), tabular
+            a = np.sort(pl, order=["read", "edge"])
+            b = np.sort(want["placements"], order=["read", "edge"])
+            for f in ("lwr", "d_llh", "pendant", "distal"):
+                assert np.allclose(a[f], b[f], rtol=1e-6, atol=1e-9), f
+            assert np.allclose(a["v_llh"], b["v_llh"], rtol=1e-9)
+            assert text == want["text"], tabular
+        dev1, host1 = capi.place_counters()
+        assert dev1 - dev0 == 2 and host1 == host0, "a batch fell back to the host back end"
+    finally:
+        ox.close()
         hx.close()
