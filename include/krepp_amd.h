@@ -43,7 +43,8 @@ typedef enum kr_status {
   KR_ERR_NO_DEVICE = -4,  /* no HIP device / HIP runtime failure               */
   KR_ERR_NOMEM = -5,
   KR_ERR_CAPACITY = -6,   /* a device-side buffer overflowed; resubmit smaller  */
-  KR_ERR_STATE = -7       /* call order (collect without submit, ...)           */
+  KR_ERR_STATE = -7,      /* call order (collect without submit, ...)           */
+  KR_ERR_UNSUPPORTED = -8 /* this batch cannot be served this way; use the general call (kr_batch_collect_text) */
 } kr_status;
 
 #define KR_MAX_HDIST_TH 16u /* k-h <= 16 (src/krepp.hpp:77-79): hd never exceeds 16 */
@@ -360,6 +361,26 @@ KR_API int kr_format_dist(const kr_host_index*, const kr_result_view*, const cha
  * on a sketch index; stream parameters multi = 1, no_filter = 1, dist_max unset. */
 KR_API int kr_format_seek(const kr_host_index*, const kr_index*, const kr_result_view*, uint32_t hdist_th,
                           const char* const* names, char** text, uint64_t* len);
+/* The same rows as TEXT written by the GPU (csrc/kr_dev_text.inc): IBatch::report_distances (src/query.cpp:158-196) ran inside the
+ * reference's parallel batch task; kr_format_dist runs on host threads at ~100 M rows/s, 45 times under the kernels on a 1000-genome
+ * index (33 rows per read).  A stream with text enabled formats its rows-only batches on the device -- SEQ_ID, reference name,
+ * "%.5f" of DIST with printf's own rounding (round-half-even of the exact binary value), "SEQ_ID\tNA\tNaN" for a read without rows --
+ * into a text buffer in HBM that is copied back as bytes: the host only write()s them, in batch order.
+ *   kr_stream_text_enable   once per stream: uploads the index's node names (once per kr_index) and sizes the stream's id and text
+ *                           buffers (max_text_bytes of page-locked host memory and as much HBM; max_id_bytes for a batch's ids)
+ *   kr_batch_submit_text    kr_batch_submit(flags | KR_ROWS_ONLY) + the reads' ids: `ids` holds them back to back in read order,
+ *                           id r = ids[id_off[r] .. id_off[r+1] - id_sep) (id_sep = 1 for NUL-terminated names, as kr_fastx_batch
+ *                           delivers them); ids and id_off may be pageable, they are staged before the call returns
+ *   kr_batch_collect_text   waits, copies the text back; *text points into the stream's page-locked buffer and stays valid until the
+ *                           next submit on this stream.  KR_ERR_CAPACITY: more text (or ids) than the buffers hold -- resubmit in
+ *                           smaller pieces; KR_ERR_UNSUPPORTED: the batch could not be formatted on the device (it was tiled: long
+ *                           sequences; or a DIST outside [0, 1000)): kr_batch_collect + kr_format_dist still serve it, no resubmit.
+ * Byte-identical to kr_format_dist (tests/test_gpu_text.py). */
+KR_API int kr_stream_text_enable(kr_stream*, const kr_host_index*, uint64_t max_text_bytes, uint64_t max_id_bytes);
+KR_API int kr_batch_submit_text(kr_stream*, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads, uint32_t flags,
+                                const char* ids, const uint32_t* id_off, uint32_t id_sep);
+KR_API int kr_batch_collect_text(kr_stream*, const char** text, uint64_t* len);
+KR_API uint32_t kr_debug_fixed5(double v, char* out); /* tests: the device formatter's "%.5f" (0: outside [0, 1000)) */
 KR_API void kr_free(void*);
 /* Page-locked host memory for read batches (KR_BASES_PINNED): what a reader fills instead of a std::string. */
 KR_API void* kr_host_alloc(uint64_t bytes);

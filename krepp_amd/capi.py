@@ -17,7 +17,7 @@ LIB_PATH = _HERE / "lib" / "libkrepp_amd.so"
 
 KR_OK = 0
 KR_ERR_ARG, KR_ERR_IO, KR_ERR_FORMAT, KR_ERR_NO_DEVICE = -1, -2, -3, -4
-KR_ERR_NOMEM, KR_ERR_CAPACITY, KR_ERR_STATE = -5, -6, -7
+KR_ERR_NOMEM, KR_ERR_CAPACITY, KR_ERR_STATE, KR_ERR_UNSUPPORTED = -5, -6, -7, -8
 KR_VIEW_HOST, KR_VIEW_DEVICE = 0, 1
 KR_BASES_HOST, KR_BASES_DEVICE, KR_TAP_ACCS, KR_TAP_HITS, KR_BASES_PINNED, KR_ROWS_ONLY = 0, 1, 2, 4, 8, 16
 
@@ -86,11 +86,11 @@ EXPORTS = [
     "kr_host_index_node_label", "kr_host_index_node_parent", "kr_host_index_node_blen",
     "kr_index_upload", "kr_index_free", "kr_index_export", "kr_index_import", "kr_index_device_bytes", "kr_index_slot_words", "kr_index_slot_format", "kr_index_broadcast",
     "kr_params_default", "kr_stream_create", "kr_stream_destroy", "kr_batch_submit", "kr_batch_wait",
-    "kr_batch_collect", "kr_batch_collect_device", "kr_batch_hits", "kr_batch_readtaps",
+    "kr_batch_collect", "kr_batch_collect_device", "kr_stream_text_enable", "kr_batch_submit_text", "kr_batch_collect_text", "kr_batch_hits", "kr_batch_readtaps",
     "kr_debug_front_end", "kr_debug_stream_move", "kr_debug_stream_addrs", "kr_debug_item_placement", "kr_debug_brent", "kr_debug_colour_classes", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
     "kr_place_tree_create", "kr_place_tree_create_lineage", "kr_place_tree_nnodes", "kr_place_summary_add",
     "kr_place_summary_text", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_stream", "kr_place_frame", "kr_place_counters",
-    "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_fastx_pgz_stats", "kr_format_dist", "kr_free", "kr_host_alloc", "kr_host_free",
+    "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_fastx_pgz_stats", "kr_format_dist", "kr_debug_fixed5", "kr_free", "kr_host_alloc", "kr_host_free",
     "kr_build_index", "kr_minimizers_cpu", "kr_minimizers_device", "kr_minimizers_free", "kr_last_error", "kr_version",
 ]
 
@@ -148,6 +148,11 @@ def load():
     lib.kr_stream_destroy.argtypes = [vp]
     lib.kr_stream_destroy.restype = None
     lib.kr_batch_submit.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32]
+    lib.kr_debug_fixed5.argtypes = [C.c_double, C.c_char_p]
+    lib.kr_debug_fixed5.restype = C.c_uint32
+    lib.kr_stream_text_enable.argtypes = [vp, vp, C.c_uint64, C.c_uint64]
+    lib.kr_batch_submit_text.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32]
+    lib.kr_batch_collect_text.argtypes = [vp, C.POINTER(vp), u64p]
     lib.kr_batch_wait.argtypes = [vp]
     lib.kr_batch_collect.argtypes = [vp, C.POINTER(KrResultView)]
     lib.kr_batch_collect_device.argtypes = [vp, C.POINTER(KrResultView)]
@@ -493,6 +498,31 @@ class Stream:
         s = C.string_at(txt, ln.value).decode()
         self.lib.kr_free(txt)
         return s
+
+    def text_enable(self, host_index, max_text_bytes, max_id_bytes):
+        """kr_stream_text_enable: this stream formats its rows-only batches on the device (csrc/kr_dev_text.inc)"""
+        check(self.lib.kr_stream_text_enable(self.h, host_index.h, int(max_text_bytes), int(max_id_bytes)))
+
+    def submit_text(self, bases, offsets, names, flags=0, sep=1):
+        """kr_batch_submit_text with the reads' ids packed back to back, `sep` NUL bytes behind each"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        enc = [n.encode() for n in names]
+        blob = (b"\0" * sep).join(enc) + b"\0" * sep
+        lens = np.fromiter((len(e) + sep for e in enc), dtype=np.uint32, count=len(enc))
+        id_off = np.zeros(len(enc) + 1, dtype=np.uint32)
+        np.cumsum(lens, out=id_off[1:])
+        ids = np.frombuffer(blob, dtype=np.uint8)
+        self._keep = (bases, offsets, ids, id_off)
+        self._flags = flags | KR_ROWS_ONLY
+        check(self.lib.kr_batch_submit_text(self.h, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, flags, ids.ctypes.data, id_off.ctypes.data, sep))
+
+    def collect_text(self):
+        """kr_batch_collect_text: the batch's report rows as the bytes the device wrote"""
+        txt = C.c_void_p()
+        ln = C.c_uint64()
+        check(self.lib.kr_batch_collect_text(self.h, C.byref(txt), C.byref(ln)))
+        return C.string_at(txt, ln.value) if ln.value else b""
 
     def format_dist(self, host_index, names):
         arr = (C.c_char_p * len(names))(*[n.encode() for n in names])

@@ -67,6 +67,47 @@ inline int64_t build_row(uint32_t rix, const BuildCfg& c)
   if (c.frac ? res <= c.r : res == c.r) return c.frac ? (int64_t)(rix / c.m) * (c.r + 1) + res : (int64_t)(rix / c.m);
   return -1;
 }
+#if defined(__HIPCC__)
+#define KR_HD __host__ __device__
+#else
+#define KR_HD
+#endif
+// round-half-even(|v| * 10^5) of the EXACT binary value of v, for 0 <= |v| < 1000: what printf("%.5f") prints, as an integer
+// (glibc rounds the exact value in the current rounding mode: nearest, ties to even).  sc = v * 1e5 rounded to double, err = the
+// rounding's exact residual (one fma: the error of a product is a double); fl = floor(sc) and fr = sc - fl are exact; since fr is a
+// multiple of ulp(sc) and |err| <= ulp(sc) / 2, the sign of (fr - 1/2) decides unless it is zero, then err's, then parity.  Shared
+// by the host formatter and the device one (kr_text_write_kernel); checked against snprintf on random values, on every j / 2^q tie
+// and next to them (tests/test_host.py).  Returns false if v is outside the range (NaN, negative, >= 1000): the caller uses printf.
+KR_HD inline bool fixed5_exact(double v, uint32_t* n_out)
+{
+  if (!(v >= 0.0 && v < 1000.0)) return false;
+  const double sc = v * 100000.0;
+  const double err = fma(v, 100000.0, -sc);
+  const double fl = floor(sc), fr = sc - fl;
+  uint32_t n = (uint32_t)fl;
+  const double t = fr - 0.5; // exact: fr in [0, 1) is a multiple of ulp(sc) <= 2^-26, and so is 1/2
+  if (t > 0.0 || (t == 0.0 && (err > 0.0 || (err == 0.0 && (n & 1u))))) ++n;
+  *n_out = n;
+  return true;
+}
+// the digits of n = round(v * 10^5) as "%.5f" text: integer part, '.', five decimals; returns the length
+KR_HD inline uint32_t fixed5_digits(uint32_t n, char* out)
+{
+  uint32_t ip = n / 100000u, fp = n - ip * 100000u;
+  char tmp[4];
+  uint32_t k = 0, o = 0;
+  do {
+    tmp[k++] = (char)('0' + ip % 10u);
+    ip /= 10u;
+  } while (ip);
+  while (k) out[o++] = tmp[--k];
+  out[o++] = '.';
+  for (int q = 4; q >= 0; --q) {
+    out[o + (uint32_t)q] = (char)('0' + fp % 10u);
+    fp /= 10u;
+  }
+  return o + 5u;
+}
 // "%.5f" of a value without going through printf: scale, round half away in integers.  printf rounds the
 // exact binary value; the two agree unless |v| * 1e5 lies within rounding noise of a tie (or v is out of the
 // fast range, NaN, infinite), where printf decides.  Checked against printf on 20 M random values.

@@ -43,6 +43,7 @@
 //   kr_dev_accumulate.inc  kernel 2: event epilogue, plane tables, records
 //   kr_dev_tiles.inc       long sequences across waves: tiles of a host batch, their merge per key, the real reads' results
 //   kr_dev_likelihood.inc  likelihood, Brent, de-duplication, selection kernels
+//   kr_dev_text.inc        the report rows as text, written on the device (kr_batch_submit_text / kr_batch_collect_text)
 //   kr_dev_place.inc       back end of `place`: ancestor accumulation, candidates, their likelihoods (kr_place_kernel)
 //   kr_dev_debug.inc       debug / tap kernels and the re-layout kernels of kr_index_upload
 // and the host side of the device ABI:
@@ -82,6 +83,7 @@ namespace {
 #include "kr_dev_accumulate.inc"
 #include "kr_dev_tiles.inc"
 #include "kr_dev_likelihood.inc"
+#include "kr_dev_text.inc"
 #include "kr_dev_place.inc"
 #include "kr_dev_debug.inc"
 

@@ -1628,6 +1628,17 @@ int kr_format_seek(const kr_host_index* h, const kr_index* dix, const kr_result_
   return KR_OK;
 }
 
+// tests: "%.5f" through the rounding the device formatter uses (fixed5_exact + fixed5_digits, kr_common.h); returns the length, 0 if
+// the value is outside the exact range
+uint32_t kr_debug_fixed5(double v, char* out)
+{
+  uint32_t n = 0;
+  if (!kr::fixed5_exact(v, &n)) return 0;
+  const uint32_t l = kr::fixed5_digits(n, out);
+  out[l] = 0;
+  return l;
+}
+
 void kr_free(void* p) { free(p); }
 
 const char* kr_last_error(void) { return kr::g_err.c_str(); }

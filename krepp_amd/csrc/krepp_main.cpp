@@ -276,8 +276,20 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
   };
   std::map<uint32_t, double> wcount; // --summarize: reference -> weighted read count (src/krepp.cpp:374-378)
   double twcount = 0;
+  // Plain `dist` rows are formatted on the device (kr_batch_submit_text / kr_batch_collect_text: the text of a batch arrives as
+  // bytes in the stream's page-locked buffer) and written by the WORKER itself, straight from that buffer, when the batch's turn
+  // has come: `next_seq` is the batch the output is waiting for (advanced by the writer thread, which still orders the batches).
+  // KR_CLI_HOST_TEXT=1: the host formatter (kr_format_dist) as before round 5.
+  const bool dev_text = !place && !seek && !summarize && !getenv("KR_CLI_HOST_TEXT");
+  uint64_t next_seq = 0;
 
+  // KR_CLI_TIMING: when things happened, in seconds since the query phase began
+  auto at = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  std::atomic<int> worker_ids{0};
   auto worker = [&](int g) {
+    const int wid = worker_ids++;
+    double t_ready = 0, t_first = -1, t_last = 0;
+    uint64_t njobs = 0;
     kr_stream* st = nullptr;
     uint64_t max_records = (uint64_t)max_reads * (place ? 128 : 64);
     if (const char* e = getenv("KR_DEBUG_CLI_RECORDS")) max_records = strtoull(e, nullptr, 10); // tests: force the split-and-retry path
@@ -288,6 +300,17 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
       cv_done.notify_all();
       return;
     }
+    bool text_on = false;
+    if (dev_text) { // room for 1.5 KB of rows per read (33 rows of ~28 bytes on a 1000-genome index) and 64 bytes of id; a batch with
+                    // more is split like one with too many records (KR_ERR_CAPACITY below)
+      const char* tpr = getenv("KR_CLI_TEXT_PER_READ"); // (tests: a buffer that is too small)
+      const uint64_t tb = tpr ? std::max<uint64_t>(4096, (uint64_t)max_reads * strtoull(tpr, nullptr, 10)) : std::max<uint64_t>(32ull << 20, (uint64_t)max_reads * 1536ull);
+      if (kr_stream_text_enable(st, hx, tb, std::max<uint64_t>(1ull << 20, (uint64_t)max_reads * 64)) == 0)
+        text_on = true;
+      else
+        fprintf(stderr, "[krepp_amd] report text on the host: %s\n", kr_last_error());
+    }
+    t_ready = at();
     // reads per submit this worker currently trusts: halved when a submit overflows a device buffer, doubled again
     // after a run of successes -- data with hundreds of rows per read settle at a piece size instead of failing a
     // full-size submit (and every intermediate size) for every batch
@@ -306,6 +329,17 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
       const std::vector<const char*>& nm = j->names;
       std::string text;
       std::vector<kr_placement> pls;
+      bool my_turn = false; // this worker holds the output (plain `dist` with device text: rows are written as they arrive)
+      auto emit = [&](const char* p, size_t n) {
+        if (!my_turn) {
+          std::unique_lock<std::mutex> lk(mu);
+          cv_done.wait(lk, [&] { return next_seq == j->seq || !worker_err.empty(); });
+          my_turn = true;
+        }
+        auto t_w = now();
+        if (n && worker_err.empty()) fwrite(p, 1, n, out);
+        ns_write += since(t_w);
+      };
       // reads [lo, hi) of the job; a batch that overflows a device-side buffer (KR_ERR_CAPACITY: unusually many
       // table hits or records per read) is resubmitted in halves, as include/krepp_amd.h prescribes
       std::function<int(size_t, size_t)> run = [&](size_t lo, size_t hi) -> int {
@@ -322,9 +356,24 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
         auto t_dev = now();
         // dist rows / the summary need (leaf, selected, DIST) only: nothing else is copied back; place keeps its records
         // on the device; seek also reads the k-mer counts
-        int rc = kr_batch_submit(st, j->bases.data() + j->offsets[lo], offs.data(), (uint32_t)(hi - lo),
-                                 KR_BASES_HOST | (place ? KR_TAP_ACCS : (seek ? 0u : KR_ROWS_ONLY)));
-        if (!rc) rc = place ? kr_batch_wait(st) : kr_batch_collect(st, &rv); // place: the records stay on the device
+        int rc;
+        const char* dtext = nullptr;
+        uint64_t dlen = 0;
+        bool on_device = false;
+        if (text_on) {
+          std::vector<uint32_t> id_off(hi - lo + 1);
+          for (size_t i = lo; i < hi; ++i) id_off[i - lo] = (uint32_t)(nm[i] - j->name_blob.data());
+          id_off[hi - lo] = hi < nm.size() ? (uint32_t)(nm[hi] - j->name_blob.data()) : (uint32_t)j->name_blob.size();
+          rc = kr_batch_submit_text(st, j->bases.data() + j->offsets[lo], offs.data(), (uint32_t)(hi - lo), KR_BASES_HOST, j->name_blob.data(),
+                                    id_off.data(), 1);
+          if (!rc) rc = kr_batch_collect_text(st, &dtext, &dlen);
+          on_device = rc == 0;
+          if (rc == KR_ERR_UNSUPPORTED) rc = kr_batch_collect(st, &rv); // (a tiled batch: its rows as record slots, formatted below)
+        } else {
+          rc = kr_batch_submit(st, j->bases.data() + j->offsets[lo], offs.data(), (uint32_t)(hi - lo),
+                               KR_BASES_HOST | (place ? KR_TAP_ACCS : (seek ? 0u : KR_ROWS_ONLY)));
+          if (!rc) rc = place ? kr_batch_wait(st) : kr_batch_collect(st, &rv); // place: the records stay on the device
+        }
         ns_dev += since(t_dev);
         auto t_fmt = now();
         if (rc == KR_ERR_CAPACITY && hi - lo > 1) {
@@ -335,6 +384,10 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
           return rc ? rc : run(mid, hi);
         }
         if (!rc && seek) rc = kr_format_seek(hx, dix[g], &rv, p.hdist_th, nm.data() + lo, &txt, &len);
+        if (!rc && on_device) {
+          emit(dtext, dlen);
+          return 0;
+        }
         if (!rc && !place && !seek && !summarize) rc = kr_format_dist(hx, &rv, nm.data() + lo, &txt, &len);
         if (!rc && summarize && !place) { // each read shares one unit among the references it keeps (src/query.cpp:168-170)
           std::lock_guard<std::mutex> lk(mu);
@@ -357,13 +410,18 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
           }
           kr_free(pp);
         }
-        if (!rc && txt) text.append(txt, len);
+        if (!rc && txt && dev_text)
+          emit(txt, len); // (in order with the pieces the device wrote)
+        else if (!rc && txt)
+          text.append(txt, len);
         kr_free(txt);
         ns_fmt += since(t_fmt);
         if (!rc && piece != SIZE_MAX && ++streak >= 16) piece = piece > SIZE_MAX / 2 ? SIZE_MAX : piece * 2, streak = 0;
         return rc;
       };
       const int rc = run(0, j->names.size());
+      t_last = at(), ++njobs;
+      if (t_first < 0) t_first = t_last;
       std::lock_guard<std::mutex> lk(mu);
       if (rc) {
         worker_err = kr_last_error();
@@ -375,6 +433,7 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
       finished[j->seq] = j;
       cv_done.notify_all();
     }
+    if (timing) fprintf(stderr, "[timing] worker %d: stream ready at %.3f s, first batch done at %.3f s, last of %llu at %.3f s\n", wid, t_ready, t_first, (unsigned long long)njobs, t_last);
     kr_stream_destroy(st);
   };
   // two workers (each with its own stream) per GPU: one formats its rows while the other's batch is on the device.  (`place` on a
@@ -429,6 +488,11 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
       }
       delete j;
       ++next;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        next_seq = next;
+      }
+      cv_done.notify_all();
       cv_work.notify_all();
     }
   });
@@ -476,6 +540,7 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
     if (!b.more) break;
   }
   kr_fastx_close(fx);
+  if (timing) fprintf(stderr, "[timing] reader: end of input at %.3f s (%llu batches)\n", at(), (unsigned long long)nbatches);
   {
     std::lock_guard<std::mutex> lk(mu);
     eof = true;

@@ -72,13 +72,16 @@ exe = os.path.join(root, "krepp_amd", "lib", "krepp")
 out_file = os.path.join(work, "out.txt")
 configs = [
     ("dist", [], {}, out_file),
+    ("dist", [], {"KR_CLI_HOST_TEXT": "1"}, out_file),  # the host formatter of rounds 1-4, same box
     ("dist", [], {"KR_CLI_BATCH_READS": "65536"}, out_file),
-    ("dist", [], {"KR_CLI_BATCH_READS": "4194304"}, out_file),
+    ("dist", [], {"KR_CLI_BATCH_READS": "1048576"}, out_file),
     ("dist", [], {"KR_CLI_WORKERS_PER_GPU": "3"}, out_file),
     ("dist", [], {}, "/dev/null"),
     ("dist", ["--summarize"], {}, out_file),
     ("dist", ["--no-multi"], {}, out_file),
 ]
+if os.environ.get("KR_TIME_CLI_CONFIGS"):  # e.g. "0,5,7"
+    configs = [configs[int(i)] for i in os.environ["KR_TIME_CLI_CONFIGS"].split(",")]
 for sub, extra, env, outp in configs:
     t = time.time()
     r = subprocess.run([exe, sub, "-i", idx, "-q", fq, "-o", outp] + extra, capture_output=True, text=True, env=dict(os.environ, KR_CLI_TIMING="1", **env))
@@ -88,7 +91,7 @@ for sub, extra, env, outp in configs:
     size = os.path.getsize(outp) / 1e9 if outp != "/dev/null" and os.path.exists(outp) else 0.0
     print(f"{sub} {' '.join(extra)} {env} -> {outp if outp == '/dev/null' else 'file'}: rc {r.returncode}, wall {dt:.2f} s, query phase "
           f"{el[0] if el else float('nan'):.2f} s = {n / el[0] / 1e6 if el else float('nan'):.1f} M reads/s, index load + start-up {dt - (el[0] if el else 0):.1f} s, "
-          f"output {size:.2f} GB", flush=True)
+          f"output {size:.2f} GB ({size / el[0] if el else 0:.2f} GB/s of text)", flush=True)
     for l in lines:
         print("   ", l, flush=True)
     if r.returncode:

@@ -416,6 +416,39 @@ def test_round2_entry_points_reject_bad_arguments_without_gpu(capi):
     lib.kr_host_free(None)  # a no-op
 
 
+def test_device_formatter_rounding_is_printfs(capi):
+    """"%.5f" as the device formatter prints it (fixed5_exact / fixed5_digits, csrc/kr_common.h: round-half-even of the exact binary
+    value through one fma) against C's own conversion (Python's % operator calls it: correctly rounded): random values over the
+    minimiser's range and beyond, every exact tie j / 2^q with its two neighbours, the decimal ties (i + 1/2) / 10^5 as doubles."""
+    import ctypes as C
+    import random
+    lib = capi.load()
+    buf = C.create_string_buffer(64)
+    def chk(v):
+        n = lib.kr_debug_fixed5(v, buf)
+        assert n and buf.value.decode() == "%.5f" % v, (v.hex(), buf.value, "%.5f" % v)
+    rng = random.Random(5)
+    for _ in range(200_000):
+        u = rng.random()
+        chk(u * 0.5), chk(u * u * u * 1e-3), chk(u * 999.99)
+    for q in range(1, 27):
+        for j in range(0, 1 << min(q, 11)):
+            v = j / float(1 << q)
+            chk(v), chk(np.nextafter(v, 1.0)), chk(np.nextafter(v, -1.0) if v > 0 else 0.0)
+    for i in range(0, 60_000, 7):
+        v = (i + 0.5) / 1e5
+        chk(v), chk(float(np.nextafter(v, 1.0))), chk(float(np.nextafter(v, 0.0)))
+    for v in (0.0, 1e-10, 0.5, 0.499995, 9.999995, 99.999995, 999.99999):
+        chk(v)
+    for v in (-1e-9, 1000.0, float("nan"), float("inf")):
+        assert lib.kr_debug_fixed5(v, buf) == 0
+    # the text entry points check their arguments before anything touches a device
+    txt, ln = C.c_void_p(), C.c_uint64()
+    assert lib.kr_stream_text_enable(None, None, 1, 1) == capi.KR_ERR_ARG
+    assert lib.kr_batch_submit_text(None, None, None, 1, 0, None, None, 1) == capi.KR_ERR_ARG
+    assert lib.kr_batch_collect_text(None, C.byref(txt), C.byref(ln)) == capi.KR_ERR_ARG
+
+
 def test_cli_usage_errors(capi):
     exe = os.path.join(ROOT, "krepp_amd", "lib", "krepp")
     r = subprocess.run([exe, "seek"], capture_output=True, text=True)

@@ -354,6 +354,13 @@ def test_cli_dist_on_a_file_large_enough_for_the_parallel_reader(po, toy_index_d
                         env=dict(os.environ, KR_DEBUG_CLI_RECORDS="20000"))
     assert r2.returncode == 0, r2.stderr
     assert r2.stdout.splitlines()[2:] == got
+    # (round 5) the rows above were written as text by the GPU (kr_batch_submit_text / kr_batch_collect_text); the host formatter
+    # (KR_CLI_HOST_TEXT=1: kr_format_dist on the box's CPUs, as before) and a text buffer too small for a batch (32 bytes per read:
+    # KR_ERR_CAPACITY, the workers settle at a smaller piece) give the same bytes
+    for env in (dict(KR_CLI_HOST_TEXT="1"), dict(KR_CLI_TEXT_PER_READ="32")):
+        r3 = subprocess.run([exe, "dist", "-i", toy_index_dir, "-q", str(fq)], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r3.returncode == 0, r3.stderr
+        assert r3.stdout.splitlines()[2:] == got, env
 
 
 @pytest.mark.gpu
