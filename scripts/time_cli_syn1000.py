@@ -73,6 +73,7 @@ out_file = os.path.join(work, "out.txt")
 configs = [
     ("dist", [], {}, out_file),
     ("dist", [], {"KR_CLI_HOST_TEXT": "1"}, out_file),  # the host formatter of rounds 1-4, same box
+    ("dist", [], {"KR_CLI_SERIAL_WRITE": "1"}, out_file),  # device text, batches written one after the other
     ("dist", [], {"KR_CLI_BATCH_READS": "65536"}, out_file),
     ("dist", [], {"KR_CLI_BATCH_READS": "1048576"}, out_file),
     ("dist", [], {"KR_CLI_WORKERS_PER_GPU": "3"}, out_file),
