@@ -347,6 +347,12 @@ typedef struct kr_fastx_batch {
 } kr_fastx_batch;
 KR_API int kr_fastx_open(const char* path, kr_fastx** out);
 KR_API int kr_fastx_next(kr_fastx*, uint64_t min_bases, kr_fastx_batch* out);
+/* The batch kr_fastx_next just returned changes hands (what QSeq gives IBatch by swap, src/query.cpp:32-33): the kr_fastx_batch's
+ * pointers stay valid, nothing is copied, until kr_fastx_release hands the buffers back for reuse -- from any thread, before
+ * kr_fastx_close.  For consumers that keep several batches in flight (the CLI's workers). */
+typedef struct kr_fastx_held kr_fastx_held;
+KR_API int kr_fastx_detach(kr_fastx*, kr_fastx_held** out);
+KR_API void kr_fastx_release(kr_fastx*, kr_fastx_held*);
 KR_API uint64_t kr_fastx_parallel_chunks(const kr_fastx*); /* chunks taken from the thread pool so far */
 /* ordinary gzip input (csrc/kr_pgz.inc): chunks handed out with their records parsed by the pool / chunks whose speculative start
  * the verified stream did not pass through (their range was inflated by the reader) / gaps closed by the reader */

@@ -90,7 +90,7 @@ EXPORTS = [
     "kr_debug_front_end", "kr_debug_stream_move", "kr_debug_stream_addrs", "kr_debug_item_placement", "kr_debug_brent", "kr_debug_colour_classes", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
     "kr_place_tree_create", "kr_place_tree_create_lineage", "kr_place_tree_nnodes", "kr_place_summary_add",
     "kr_place_summary_text", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_stream", "kr_place_frame", "kr_place_counters",
-    "kr_fastx_open", "kr_fastx_next", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_fastx_pgz_stats", "kr_format_dist", "kr_debug_fixed5", "kr_free", "kr_host_alloc", "kr_host_free",
+    "kr_fastx_open", "kr_fastx_next", "kr_fastx_detach", "kr_fastx_release", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_fastx_pgz_stats", "kr_format_dist", "kr_debug_fixed5", "kr_free", "kr_host_alloc", "kr_host_free",
     "kr_build_index", "kr_minimizers_cpu", "kr_minimizers_device", "kr_minimizers_free", "kr_last_error", "kr_version",
 ]
 
@@ -182,6 +182,9 @@ def load():
     lib.kr_place_counters.restype = None
     lib.kr_fastx_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.kr_fastx_next.argtypes = [vp, C.c_uint64, C.POINTER(KrFastxBatch)]
+    lib.kr_fastx_detach.argtypes = [vp, C.POINTER(vp)]
+    lib.kr_fastx_release.argtypes = [vp, vp]
+    lib.kr_fastx_release.restype = None
     lib.kr_fastx_close.argtypes = [vp]
     lib.kr_fastx_close.restype = None
     lib.kr_format_dist.argtypes = [vp, C.POINTER(KrResultView), C.POINTER(C.c_char_p), C.POINTER(vp), u64p]
@@ -563,25 +566,44 @@ def colour_classes(pse, node_kind):
     return cls, out, lists[: nl.value]
 
 
-def read_fastx(path, min_bases=76800, stats=None):
-    """All records of a FASTA/FASTQ(.gz) file via the library's reader: (names, bases, offsets)."""
+def read_fastx(path, min_bases=76800, stats=None, detach=0):
+    """All records of a FASTA/FASTQ(.gz) file via the library's reader: (names, bases, offsets).
+    detach = K > 0: every batch is taken over (kr_fastx_detach), read only when K further batches have been parsed, then handed
+    back (kr_fastx_release) -- the way the CLI's workers hold batches in flight."""
     lib = load()
     lib.kr_fastx_parallel_chunks.restype = C.c_uint64
     lib.kr_fastx_parallel_chunks.argtypes = [C.c_void_p]
     h = C.c_void_p()
     check(lib.kr_fastx_open(os.fsencode(str(path)), C.byref(h)))
     names, chunks, lens = [], [], []
+
+    def take(b):
+        if b.nreads:
+            offs = np.ctypeslib.as_array(b.offsets, shape=(b.nreads + 1,)).copy()
+            chunks.append(np.ctypeslib.as_array(b.bases, shape=(int(offs[-1]),)).copy() if offs[-1] else np.zeros(0, np.uint8))
+            lens.extend(np.diff(offs).tolist())
+            names.extend(b.names[i].decode() for i in range(b.nreads))
+
+    held = []
     try:
         while True:
             b = KrFastxBatch()
             check(lib.kr_fastx_next(h, min_bases, C.byref(b)))
-            if b.nreads:
-                offs = np.ctypeslib.as_array(b.offsets, shape=(b.nreads + 1,)).copy()
-                chunks.append(np.ctypeslib.as_array(b.bases, shape=(int(offs[-1]),)).copy() if offs[-1] else np.zeros(0, np.uint8))
-                lens.extend(np.diff(offs).tolist())
-                names.extend(b.names[i].decode() for i in range(b.nreads))
+            if detach:
+                hp = C.c_void_p()
+                check(lib.kr_fastx_detach(h, C.byref(hp)))
+                held.append((b, hp))
+                while len(held) > detach:
+                    ob, ohp = held.pop(0)
+                    take(ob)
+                    lib.kr_fastx_release(h, ohp)
+            else:
+                take(b)
             if not b.more:
                 break
+        for ob, ohp in held:
+            take(ob)
+            lib.kr_fastx_release(h, ohp)
     finally:
         if stats is not None:
             stats["parallel_chunks"] = int(lib.kr_fastx_parallel_chunks(h))

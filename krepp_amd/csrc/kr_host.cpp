@@ -1181,6 +1181,14 @@ struct BgzfSource {
   }
 };
 
+struct kr_fastx_held { // the buffers of one batch, owned by the caller between kr_fastx_detach and kr_fastx_release
+  std::vector<uint8_t> bases;
+  std::vector<uint64_t> offsets;
+  std::string name_blob;
+  std::vector<size_t> name_off;
+  std::vector<const char*> name_ptrs;
+};
+
 struct kr_fastx {
   gzFile f = nullptr;
   std::unique_ptr<BgzfSource> bgzf; // block-gzipped input: members inflated in parallel
@@ -1201,6 +1209,10 @@ struct kr_fastx {
   std::string name_blob;
   std::vector<size_t> name_off;
   std::vector<const char*> name_ptrs;
+  // batches taken over by the caller (kr_fastx_detach) come back here with their buffers (kr_fastx_release, any thread): the next
+  // batch is built in them, so that a chunk's parse never starts in freshly mapped memory (see FqChunk)
+  std::mutex held_mu;
+  std::vector<kr_fastx_held*> recycled;
 
   bool records_mode() const { return (pgz && pgz->st.parsed_mode) || (bgzf && bgzf->st.parsed_mode); }
 
@@ -1422,35 +1434,67 @@ int kr_fastx_open(const char* path, kr_fastx** out)
 int kr_fastx_next(kr_fastx* r, uint64_t min_bases, kr_fastx_batch* out)
 {
   if (!r || !out) return kr::fail(KR_ERR_ARG, "kr_fastx_next: null argument");
+  if (r->bases.capacity() == 0) { // the last batch was detached: build this one in buffers that came back
+    kr_fastx_held* h = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(r->held_mu);
+      if (!r->recycled.empty()) h = r->recycled.back(), r->recycled.pop_back();
+    }
+    if (h) {
+      r->bases.swap(h->bases), r->offsets.swap(h->offsets), r->name_blob.swap(h->name_blob), r->name_off.swap(h->name_off), r->name_ptrs.swap(h->name_ptrs);
+      delete h;
+    }
+  }
   r->bases.clear();
   r->offsets.assign(1, 0);
   r->name_blob.clear();
   r->name_off.clear();
   uint64_t bpc = 0;
-  if (r->pool) { // one chunk of about 2 * min_bases bytes of input per batch (about min_bases bases of ordinary FASTQ)
+  if (r->pool) { // one chunk of about 2 * min_bases bytes of input per batch (about min_bases bases of ordinary FASTQ), at most 96 MB:
+                 // a larger batch is put together from several chunks (the first by swap, the others appended), so that a
+                 // million-read batch is still parsed by the whole pool and not by one thread per batch
     FqPool& P = *r->pool;
-    if (!P.chunk_bytes) P.chunk_bytes = std::max<uint64_t>(4096, 2 * min_bases);
-    P.issue();
-    uint64_t resume = P.next_off; // where sequential parsing takes over if no chunk is left
-    bool fall_back = P.inflight.empty();
-    if (!fall_back) {
+    if (!P.chunk_bytes) {
+      const char* cm = getenv("KR_FASTX_CHUNK_MAX"); // (tests: batches of many small chunks)
+      P.chunk_bytes = std::min<uint64_t>(std::max<uint64_t>(4096, 2 * min_bases), cm ? std::max<uint64_t>(4096, strtoull(cm, nullptr, 10)) : (96ull << 20));
+    }
+    bool fall_back = false;
+    uint64_t resume = 0;
+    for (;;) {
+      P.issue();
+      resume = P.next_off; // where sequential parsing takes over if no chunk is left
+      if (P.inflight.empty()) {
+        fall_back = r->name_off.empty(); // (a batch in hand goes out first: the next call falls back)
+        break;
+      }
       std::unique_ptr<FqChunk> c = std::move(P.inflight.front());
       P.inflight.pop_front();
       {
         std::unique_lock<std::mutex> lk(P.mu);
         P.cv_ready.wait(lk, [&] { return c->ready; });
       }
-      r->bases.swap(c->bases);
-      r->offsets.swap(c->offsets);
-      r->name_blob.swap(c->name_blob);
-      r->name_off.swap(c->name_off);
-      bpc = r->bases.size();
-      if (!c->ok) fall_back = true, resume = c->clean_end;
-      else {
-        r->pool_chunks++;
-        if (P.spare.size() < 2 * P.depth) P.spare.push_back(std::move(c)); // (with the batch's previous vectors: their capacity serves the next chunk)
-        P.issue();
+      if (r->name_off.empty()) { // the batch's first chunk: its vectors become the batch's
+        r->bases.swap(c->bases);
+        r->offsets.swap(c->offsets);
+        r->name_blob.swap(c->name_blob);
+        r->name_off.swap(c->name_off);
+      } else { // behind what the batch holds
+        const uint64_t b0 = r->bases.size();
+        const size_t n0 = r->name_blob.size();
+        r->bases.insert(r->bases.end(), c->bases.begin(), c->bases.end());
+        for (size_t i = 1; i < c->offsets.size(); ++i) r->offsets.push_back(b0 + c->offsets[i]);
+        r->name_blob.append(c->name_blob);
+        for (size_t o : c->name_off) r->name_off.push_back(n0 + o);
       }
+      bpc = r->bases.size();
+      if (!c->ok) {
+        fall_back = true, resume = c->clean_end;
+        break;
+      }
+      r->pool_chunks++;
+      if (P.spare.size() < 2 * P.depth) P.spare.push_back(std::move(c)); // (with the batch's previous vectors: their capacity serves the next chunk)
+      P.issue();
+      if (bpc >= min_bases) break;
     }
     if (fall_back) { // the rest of the input goes through the sequential reader
       P.shutdown();
@@ -1498,6 +1542,36 @@ int kr_fastx_next(kr_fastx* r, uint64_t min_bases, kr_fastx_batch* out)
   return KR_OK;
 }
 
+// The batch kr_fastx_next just returned changes hands: its buffers leave the reader (the pointers of the kr_fastx_batch stay valid,
+// nothing is copied) until kr_fastx_release gives them back -- from any thread, before kr_fastx_close.  What QSeq hands to IBatch by
+// swap (src/query.cpp:32-33), for a consumer that keeps several batches in flight.
+int kr_fastx_detach(kr_fastx* r, kr_fastx_held** out)
+{
+  if (!r || !out) return kr::fail(KR_ERR_ARG, "kr_fastx_detach: null argument");
+  kr_fastx_held* h = new (std::nothrow) kr_fastx_held();
+  if (!h) return kr::fail(KR_ERR_NOMEM, "kr_fastx_detach: out of memory");
+  h->bases = std::move(r->bases), h->offsets = std::move(r->offsets), h->name_blob = std::move(r->name_blob);
+  h->name_off = std::move(r->name_off), h->name_ptrs = std::move(r->name_ptrs);
+  r->bases = std::vector<uint8_t>(), r->offsets = std::vector<uint64_t>(), r->name_blob = std::string(); // (moved-from: make the emptiness definite)
+  r->name_off = std::vector<size_t>(), r->name_ptrs = std::vector<const char*>();
+  // (a short blob lives inside the string object and moved with it: the pointer array -- same address as before -- is refreshed)
+  for (size_t i = 0; i < h->name_off.size() && i < h->name_ptrs.size(); ++i) h->name_ptrs[i] = h->name_blob.c_str() + h->name_off[i];
+  *out = h;
+  return KR_OK;
+}
+void kr_fastx_release(kr_fastx* r, kr_fastx_held* h)
+{
+  if (!h) return;
+  if (r) {
+    std::lock_guard<std::mutex> lk(r->held_mu);
+    if (r->recycled.size() < 16) {
+      r->recycled.push_back(h);
+      return;
+    }
+  }
+  delete h;
+}
+
 uint64_t kr_fastx_parallel_chunks(const kr_fastx* r) { return r ? (r->pgz ? r->pgz->chunks_used : r->pool_chunks) : 0; }
 // (tests) ordinary gzip input: chunks whose speculative start was used / thrown away, gaps inflated sequentially
 void kr_fastx_pgz_stats(const kr_fastx* r, uint64_t* used, uint64_t* discarded, uint64_t* gaps)
@@ -1510,6 +1584,8 @@ void kr_fastx_pgz_stats(const kr_fastx* r, uint64_t* used, uint64_t* discarded, 
 void kr_fastx_close(kr_fastx* r)
 {
   if (!r) return;
+  for (kr_fastx_held* h : r->recycled) delete h;
+  r->recycled.clear();
   if (r->pool) r->pool->shutdown();
   if (r->bgzf) r->bgzf->shutdown();
   if (r->pgz) r->pgz->shutdown();

@@ -139,10 +139,19 @@ static Args parse(int argc, char** argv)
 
 struct Job {
   uint64_t seq = 0;
-  std::vector<uint8_t> bases;
-  std::vector<uint64_t> offsets;
-  std::string name_blob;            // the names, NUL-terminated, back to back (one allocation instead of one per read)
-  std::vector<const char*> names;   // pointers into name_blob
+  // the batch as views: into a batch the reader handed over whole (kr_fastx_detach: nothing copied, given back by the worker
+  // when the batch is done) or into the copies below (a reader batch cut into several jobs)
+  const uint8_t* bases = nullptr;
+  const uint64_t* offsets = nullptr;  // [n + 1], offsets[0] is the job's first base within `bases`
+  const char* const* names = nullptr; // [n] NUL-terminated, back to back in one buffer, in order
+  size_t n = 0;
+  const char* blob = nullptr;         // = names[0]: the names' buffer
+  size_t blob_bytes = 0;
+  kr_fastx_held* held = nullptr;
+  std::vector<uint8_t> own_bases;
+  std::vector<uint64_t> own_offsets;
+  std::string own_blob;
+  std::vector<const char*> own_names;
   std::string text;
   std::vector<kr_placement> pls; // place --summarize: the placements, `read` = global read number
   uint64_t first_read = 0;
@@ -302,6 +311,7 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
   std::atomic<int> worker_ids{0};
   int workers_ready = 0;
   std::vector<kr_stream*> streams_to_free;
+  kr_fastx* fx = nullptr; // (opened when the workers are ready; they hand batches back to it)
   auto worker = [&](int g) {
     const int wid = worker_ids++;
     double t_ready = 0, t_first = -1, t_last = 0;
@@ -348,7 +358,9 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
         todo.pop_front();
       }
       cv_work.notify_all(); // the reader may be waiting for queue space
-      const std::vector<const char*>& nm = j->names;
+      const char* const* nm = j->names;
+      const size_t job_n = j->n;             // (`j` may be gone once its rows have taken their place in the output)
+      kr_fastx_held* const job_held = j->held;
       std::string text;
       std::vector<kr_placement> pls;
       bool my_turn = false; // this worker holds the output (plain `dist` with device text: rows are written as they arrive)
@@ -412,15 +424,15 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
         bool on_device = false;
         if (text_on) {
           std::vector<uint32_t> id_off(hi - lo + 1);
-          for (size_t i = lo; i < hi; ++i) id_off[i - lo] = (uint32_t)(nm[i] - j->name_blob.data());
-          id_off[hi - lo] = hi < nm.size() ? (uint32_t)(nm[hi] - j->name_blob.data()) : (uint32_t)j->name_blob.size();
-          rc = kr_batch_submit_text(st, j->bases.data() + j->offsets[lo], offs.data(), (uint32_t)(hi - lo), KR_BASES_HOST, j->name_blob.data(),
+          for (size_t i = lo; i < hi; ++i) id_off[i - lo] = (uint32_t)(nm[i] - j->blob);
+          id_off[hi - lo] = hi < j->n ? (uint32_t)(nm[hi] - j->blob) : (uint32_t)j->blob_bytes;
+          rc = kr_batch_submit_text(st, j->bases + j->offsets[lo], offs.data(), (uint32_t)(hi - lo), KR_BASES_HOST, j->blob,
                                     id_off.data(), 1);
           if (!rc) rc = kr_batch_collect_text(st, &dtext, &dlen);
           on_device = rc == 0;
           if (rc == KR_ERR_UNSUPPORTED) rc = kr_batch_collect(st, &rv); // (a tiled batch: its rows as record slots, formatted below)
         } else {
-          rc = kr_batch_submit(st, j->bases.data() + j->offsets[lo], offs.data(), (uint32_t)(hi - lo),
+          rc = kr_batch_submit(st, j->bases + j->offsets[lo], offs.data(), (uint32_t)(hi - lo),
                                KR_BASES_HOST | (place ? KR_TAP_ACCS : (seek ? 0u : KR_ROWS_ONLY)));
           if (!rc) rc = place ? kr_batch_wait(st) : kr_batch_collect(st, &rv); // place: the records stay on the device
         }
@@ -433,12 +445,12 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
           rc = run(lo, mid);
           return rc ? rc : run(mid, hi);
         }
-        if (!rc && seek) rc = kr_format_seek(hx, dix[g], &rv, p.hdist_th, nm.data() + lo, &txt, &len);
+        if (!rc && seek) rc = kr_format_seek(hx, dix[g], &rv, p.hdist_th, nm + lo, &txt, &len);
         if (!rc && on_device) {
-          emit(dtext, dlen, lo == 0 && hi == j->names.size());
+          emit(dtext, dlen, lo == 0 && hi == job_n);
           return 0;
         }
-        if (!rc && !place && !seek && !summarize) rc = kr_format_dist(hx, &rv, nm.data() + lo, &txt, &len);
+        if (!rc && !place && !seek && !summarize) rc = kr_format_dist(hx, &rv, nm + lo, &txt, &len);
         if (!rc && summarize && !place) { // each read shares one unit among the references it keeps (src/query.cpp:168-170)
           std::lock_guard<std::mutex> lk(mu);
           for (uint32_t r = 0; r < rv.nreads; ++r) {
@@ -452,7 +464,7 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
           int prev = (!tabular && !text.empty()) ? 1 : 0; // pieces of a batch are joined here, batches by the writer (src/krepp.cpp:474-484)
           kr_placement* pp = nullptr;
           uint64_t npp = 0;
-          rc = kr_place_stream(hx, dix[g], ptree, st, (uint32_t)(hi - lo), offs.data(), nm.data() + lo, &p, tabular, &prev, &txt, &len,
+          rc = kr_place_stream(hx, dix[g], ptree, st, (uint32_t)(hi - lo), offs.data(), nm + lo, &p, tabular, &prev, &txt, &len,
                                tabular == 2 ? &pp : nullptr, tabular == 2 ? &npp : nullptr);
           for (uint64_t i = 0; i < npp; ++i) {
             pp[i].read = (uint32_t)(j->first_read + lo + pp[i].read);
@@ -469,7 +481,8 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
         if (!rc && piece != SIZE_MAX && ++streak >= 16) piece = piece > SIZE_MAX / 2 ? SIZE_MAX : piece * 2, streak = 0;
         return rc;
       };
-      const int rc = run(0, j->names.size());
+      const int rc = run(0, job_n);
+      if (job_held) kr_fastx_release(fx, job_held); // (the batch's buffers go back to the reader)
       t_last = at(), ++njobs;
       if (t_first < 0) t_first = t_last;
       if (handed_over) continue; // (its rows are in the file; the writer thread has the job)
@@ -516,10 +529,10 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
         finished.erase(it);
       }
       if (tabular == 2) {
-        const uint32_t end_group = (uint32_t)(j->first_read + j->names.size()) >> 9;
+        const uint32_t end_group = (uint32_t)(j->first_read + j->n) >> 9;
         carry.insert(carry.end(), j->pls.begin(), j->pls.end());
         size_t cut = carry.size();
-        if ((j->first_read + j->names.size()) & 511u)
+        if ((j->first_read + j->n) & 511u)
           while (cut > 0 && (carry[cut - 1].read >> 9) == end_group) --cut;
         if (kr_place_summary_add(ptree, carry.data(), cut, pwcount.data(), &ptwcount)) {
           std::lock_guard<std::mutex> lk(mu);
@@ -556,7 +569,6 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
   if (seek) fprintf(stderr, "Seeking query sequences in the sketch...\n");
   if (!place && !seek) fprintf(stderr, "Estimating distances between given sequences and references...\n");
   t0 = std::chrono::steady_clock::now();
-  kr_fastx* fx = nullptr;
   if (kr_fastx_open(a.get("--query").c_str(), &fx)) error_exit(kr_last_error());
   uint64_t nbatches = 0, nreads_total = 0;
   for (;;) {
@@ -572,17 +584,26 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
       while (r1 < b.nreads && r1 - r0 < max_reads && b.offsets[r1 + 1] - b.offsets[r0] <= max_bases) ++r1;
       if (r1 == r0) error_exit("A query sequence is longer than the supported maximum per batch");
       Job* j = new Job();
-      j->bases.assign(b.bases + b.offsets[r0], b.bases + b.offsets[r1]);
-      j->offsets.resize(r1 - r0 + 1);
-      for (uint32_t i = r0; i <= r1; ++i) j->offsets[i - r0] = b.offsets[i] - b.offsets[r0];
-      { // the reader keeps a batch's names back to back in one buffer, in order (include/krepp_amd.h)
+      j->n = r1 - r0;
+      if (r0 == 0 && r1 == b.nreads && !getenv("KR_CLI_COPY_BATCHES")) {
+        // the whole batch is one job: it changes hands as it is (QSeq gives IBatch its vectors by swap, src/query.cpp:32-33); the
+        // reader thread copies nothing and the worker gives the buffers back when the batch is done
+        if (kr_fastx_detach(fx, &j->held)) error_exit(kr_last_error());
+        j->bases = b.bases, j->offsets = b.offsets, j->names = b.names;
+      } else {
+        j->own_bases.assign(b.bases + b.offsets[r0], b.bases + b.offsets[r1]);
+        j->own_offsets.resize(r1 - r0 + 1);
+        for (uint32_t i = r0; i <= r1; ++i) j->own_offsets[i - r0] = b.offsets[i] - b.offsets[r0];
+        // the reader keeps a batch's names back to back in one buffer, in order (include/krepp_amd.h)
         const char* first = b.names[r0];
         const char* last = b.names[r1 - 1];
-        const size_t bytes = (size_t)(last - first) + strlen(last) + 1;
-        j->name_blob.assign(first, bytes);
-        j->names.resize(r1 - r0);
-        for (uint32_t i = r0; i < r1; ++i) j->names[i - r0] = j->name_blob.data() + (b.names[i] - first);
+        j->own_blob.assign(first, (size_t)(last - first) + strlen(last) + 1);
+        j->own_names.resize(r1 - r0);
+        for (uint32_t i = r0; i < r1; ++i) j->own_names[i - r0] = j->own_blob.data() + (b.names[i] - first);
+        j->bases = j->own_bases.data(), j->offsets = j->own_offsets.data(), j->names = j->own_names.data();
       }
+      j->blob = j->names[0];
+      j->blob_bytes = (size_t)(j->names[j->n - 1] - j->names[0]) + strlen(j->names[j->n - 1]) + 1;
       j->first_read = nreads_total;
       nreads_total += r1 - r0;
       {
@@ -598,7 +619,6 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
     ns_job += since(t_job);
     if (!b.more) break;
   }
-  kr_fastx_close(fx);
   if (timing) fprintf(stderr, "[timing] reader: end of input at %.3f s (%llu batches)\n", at(), (unsigned long long)nbatches);
   {
     std::lock_guard<std::mutex> lk(mu);
@@ -636,18 +656,26 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
   }
   if (out != stdout) fclose(out);
   double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  auto t_down = now();
-  for (kr_stream* st : streams_to_free) kr_stream_destroy(st);
-  for (auto* d : dix) kr_index_free(d);
-  kr_host_index_free(hx);
-  if (timing) fprintf(stderr, "[timing] initialisation after the index upload (streams, page-locked buffers) %.3f s, tear-down %.3f s\n",
-                      std::chrono::duration<double>(t0 - t_init).count(), since(t_down) / 1e9);
   fprintf(stderr, place ? "Done placing queries, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n" : seek ? "Done seeking query sequences, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n" : "Done estimating distances, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n", sec,
           sec > 0 ? nreads_total / sec : 0.0, ngpus);
   if (timing)
-    fprintf(stderr, "[timing] parse %.3f s, job hand-over (incl. waiting for queue space) %.3f s, device %.3f s, format %.3f s, write %.3f s\n",
-            ns_parse / 1e9, ns_job / 1e9, ns_dev / 1e9, ns_fmt / 1e9, ns_write / 1e9);
+    fprintf(stderr, "[timing] parse %.3f s, job hand-over (incl. waiting for queue space) %.3f s, device %.3f s, format %.3f s, write %.3f s; initialisation after the index upload (streams, page-locked buffers) %.3f s\n",
+            ns_parse / 1e9, ns_job / 1e9, ns_dev / 1e9, ns_fmt / 1e9, ns_write / 1e9, std::chrono::duration<double>(t0 - t_init).count());
   fprintf(stderr, "Total number of sequences queried: %llu\n", (unsigned long long)nreads_total);
+  // Everything is written.  Unmapping 19 GB of index, 10 GB of host tables and the page-locked buffers one by one takes 0.8-1.2 s
+  // that nobody is waiting for: the process ends here and the kernel reclaims the lot (KR_CLI_CLEAN_EXIT=1: free everything in
+  // order -- leak checkers, tests of the tear-down path).
+  if (!getenv("KR_CLI_CLEAN_EXIT")) {
+    fflush(stdout);
+    fflush(stderr);
+    _exit(0);
+  }
+  auto t_down = now();
+  kr_fastx_close(fx); // (the reader's thread pool and chunk buffers)
+  for (kr_stream* st : streams_to_free) kr_stream_destroy(st);
+  for (auto* d : dix) kr_index_free(d);
+  kr_host_index_free(hx);
+  if (timing) fprintf(stderr, "[timing] tear-down %.3f s\n", since(t_down) / 1e9);
   return 0;
 }
 

@@ -177,6 +177,25 @@ def test_parallel_fastq_reader_equals_sequential(capi, tmp_path):
                 assert par_res[2] > 10, (key, mb, par_res[2])  # the pool did parse most of the file
             if key in ("leading_junk", "fasta_only", "empty"):
                 assert par_res[2] == 0
+        if key in ("clean", "fasta_tail", "empty", "leading_junk"):  # batches held by the caller while the reader goes on (kr_fastx_detach / release)
+            for threads in ("0", "3"):
+                os.environ["KR_FASTX_THREADS"], os.environ["KR_FASTX_PAR_MIN"] = threads, "0"
+                try:
+                    n, b, o = capi.read_fastx(str(p), min_bases=1, detach=3)
+                    n5, b5, o5 = capi.read_fastx(str(p), min_bases=5000, detach=1)
+                finally:
+                    del os.environ["KR_FASTX_THREADS"], os.environ["KR_FASTX_PAR_MIN"]
+                assert n == seq_res[0] == n5 and [bytes(b[int(o[i]):int(o[i + 1])]) for i in range(len(n))] == seq_res[1]
+                assert [bytes(b5[int(o5[i]):int(o5[i + 1])]) for i in range(len(n5))] == seq_res[1]
+        # a batch put together from several chunks (what a million-read batch is: chunks are capped at 96 MB)
+        os.environ["KR_FASTX_CHUNK_MAX"] = "4096"
+        try:
+            seq_m, par_m = _read_both_ways(capi, p, 30_000)
+        finally:
+            del os.environ["KR_FASTX_CHUNK_MAX"]
+        assert par_m[0] == seq_res[0] and par_m[1] == seq_res[1], key
+        if key in ("clean", "no_final_newline", "crlf"):
+            assert par_m[2] > 10
         if key == "clean":
             assert seq_res[0] == ["r%d" % i for i in range(4000)]
             assert seq_res[1] == [r.split(b"\n")[1] for r in clean]
