@@ -1496,7 +1496,12 @@ int kr_fastx_next(kr_fastx* r, uint64_t min_bases, kr_fastx_batch* out)
       P.issue();
       if (bpc >= min_bases) break;
     }
-    if (fall_back) { // the rest of the input goes through the sequential reader
+    if (fall_back && resume >= P.size && P.size != 0) {
+      // every byte of the file went through the pool: the input is exhausted.  The pool (its threads, and gigabytes of recycled
+      // chunk buffers) is torn down by kr_fastx_close, not here: unmapping them took 0.1 s between the last batch and the end of
+      // input -- on the caller's critical path
+      r->done = true;
+    } else if (fall_back) { // the rest of the input goes through the sequential reader
       P.shutdown();
       r->pool.reset();
       if (gzseek(r->f, (z_off_t)resume, SEEK_SET) < 0) return kr::fail(KR_ERR_IO, "kr_fastx_next: seek failed in " + r->path);

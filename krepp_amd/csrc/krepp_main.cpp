@@ -287,7 +287,10 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
   auto since = [](std::chrono::steady_clock::time_point t) {
     return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count();
   };
-  std::map<uint32_t, double> wcount; // --summarize: reference -> weighted read count (src/krepp.cpp:374-378)
+  // --summarize: reference -> weighted read count (src/krepp.cpp:374-378), by colour id; every worker sums its batches in an array
+  // of its own (264 M rows per 8 M reads on a 1000-genome index: a shared map under a mutex was the whole run) and adds it here
+  // when it ends -- the reference adds per batch under `omp critical`, in whatever order the tasks finish
+  std::vector<double> wcount(summarize && !place ? (size_t)view.tree_nnodes + 2 : 0, 0.0);
   double twcount = 0;
   // Plain `dist` rows are formatted on the device (kr_batch_submit_text / kr_batch_collect_text: the text of a batch arrives as
   // bytes in the stream's page-locked buffer) and written by the WORKER itself, straight from that buffer, when the batch's turn
@@ -327,6 +330,8 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
       cv_done.notify_all();
       return;
     }
+    std::vector<double> wc_local(wcount.size(), 0.0); // --summarize: this worker's sums
+    double tw_local = 0;
     bool text_on = false;
     if (dev_text) { // room for 1.5 KB of rows per read (33 rows of ~28 bytes on a 1000-genome index) and 64 bytes of id; a batch with
                     // more is split like one with too many records (KR_ERR_CAPACITY below)
@@ -452,12 +457,16 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
         }
         if (!rc && !place && !seek && !summarize) rc = kr_format_dist(hx, &rv, nm + lo, &txt, &len);
         if (!rc && summarize && !place) { // each read shares one unit among the references it keeps (src/query.cpp:168-170)
-          std::lock_guard<std::mutex> lk(mu);
           for (uint32_t r = 0; r < rv.nreads; ++r) {
             uint32_t o = rv.read_off[r], n = rv.read_cnt[r], ns = 0;
             for (uint32_t i = o; i < o + n; ++i) ns += rv.rec_sel[i];
+            const double w = 1.0 / ns;
             for (uint32_t i = o; i < o + n; ++i)
-              if (rv.rec_sel[i]) wcount[rv.rec_key[i] >> 1] += 1.0 / ns, twcount += 1.0 / ns;
+              if (rv.rec_sel[i]) {
+                const uint32_t se = rv.rec_key[i] >> 1;
+                if (se < wc_local.size()) wc_local[se] += w;
+                tw_local += w;
+              }
           }
         }
         if (!rc && place) {
@@ -499,6 +508,8 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
     }
     if (timing) fprintf(stderr, "[timing] worker %d: stream ready %.3f s into the initialisation, first batch done at %.3f s, last of %llu at %.3f s\n", wid, t_ready, t_first, (unsigned long long)njobs, t_last);
     std::lock_guard<std::mutex> lk(mu);
+    for (size_t q = 0; q < wc_local.size(); ++q) wcount[q] += wc_local[q];
+    twcount += tw_local;
     streams_to_free.push_back(st); // (torn down with the index, after the elapsed time has been taken)
   };
   // two workers (each with its own stream) per GPU: one formats its rows while the other's batch is on the device.  (`place` on a
@@ -632,7 +643,8 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
   writer.join();
   if (!worker_err.empty()) error_exit(worker_err);
   if (summarize && !place) // src/krepp.cpp:388-393 (ascending colour id instead of hash-map order)
-    for (auto& kv : wcount) fprintf(out, "%s\t%.5f\t%.5f\n", kr_host_index_node_name(hx, kv.first), kv.second, kv.second / twcount);
+    for (uint32_t se = 0; se < wcount.size(); ++se)
+      if (wcount[se] != 0) fprintf(out, "%s\t%.5f\t%.5f\n", kr_host_index_node_name(hx, se), wcount[se], wcount[se] / twcount);
   if (tabular == 2) { // src/krepp.cpp:493-497
     char* t = nullptr;
     uint64_t l = 0;

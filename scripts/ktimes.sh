@@ -8,9 +8,9 @@ rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-inclusive --read-procs 1 --distinct-batches 1 --skip-host-path-check "$@" > $OUT/bench.log 2>&1
 python3 - <<PY
 import csv,glob,collections,re,statistics
-f=glob.glob("$OUT/**/*kernel_trace.csv",recursive=True)[0]
 d=collections.defaultdict(list)
-for r in csv.DictReader(open(f)):
+for f in glob.glob("$OUT/**/*kernel_trace.csv",recursive=True):  # (bench.py inflates its table in a child process: one trace per process)
+  for r in csv.DictReader(open(f)):
     m=re.search(r'(kr_\w+)(<[^>]*>)?', r["Kernel_Name"])
     if m: d[m.group(1)+(m.group(2) or "")].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6)
 tot=0
