@@ -854,6 +854,7 @@ struct FqPool {
     }
     return true;
   }
+  // (compiled twice: the record checks are byte loops that AVX2 takes 32 at a time; the dispatch is the loader's, at run time)
   void parse(FqChunk& c)
   {
     const size_t len = (size_t)(c.b - c.a);
