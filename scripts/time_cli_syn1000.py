@@ -97,3 +97,21 @@ for sub, extra, env, outp in configs:
         print("   ", l, flush=True)
     if r.returncode:
         print(r.stderr[-1500:])
+
+# ---- KR_TIME_CLI_TRACE=1: the default configuration once more under rocprofv3 --kernel-trace (the binary itself after `--`): the
+#      kernels of a CLI batch by name -- what the text kernels (kr_text_*) and the row compaction cost beside the rest
+if os.environ.get("KR_TIME_CLI_TRACE"):
+    import collections, csv, glob, re, statistics
+    td = os.path.join(work, "trace")
+    env = dict(os.environ, TMPDIR="/tmp", GPU_MAX_HW_QUEUES="8")
+    r = subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", td, "--", exe, "dist", "-i", idx, "-q", fq, "-o", out_file],
+                       capture_output=True, text=True, env=env)
+    d = collections.defaultdict(list)
+    for f in glob.glob(td + "/**/*kernel_trace.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            m = re.search(r"(kr_\w+)(<[^>]*>)?", row["Kernel_Name"])
+            if m:
+                d[m.group(1)].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
+    print(f"kernels of `krepp dist` (default configuration, {n} reads) under rocprofv3 --kernel-trace: name, launches, median ms, total ms", flush=True)
+    for k_, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+        print(f"    {k_:32s} {len(v):5d} {statistics.median(v):9.3f} {sum(v):10.1f}", flush=True)
