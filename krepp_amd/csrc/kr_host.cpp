@@ -1537,6 +1537,9 @@ int kr_fastx_next(kr_fastx* r, uint64_t min_bases, kr_fastx_batch* out)
     r->name_blob.push_back('\0');
   }
   if (r->bgzf_error) return kr::fail(KR_ERR_IO, "damaged block-gzipped file (a member does not inflate or fails its CRC): " + r->path);
+  if (r->pgz_error && r->pgz && r->pgz->too_dense.load())
+    return kr::fail(KR_ERR_IO, "a 4 MB piece of this gzip file inflates to more than 1 GB: more than the parallel reader keeps in memory; "
+                                "run with KR_PGZ=0 (zlib's streaming reader): " + r->path);
   if (r->pgz_error) return kr::fail(KR_ERR_IO, "damaged gzip file (the stream does not inflate, or a member fails its CRC / length check): " + r->path);
   r->name_ptrs.resize(r->name_off.size());
   for (size_t i = 0; i < r->name_off.size(); ++i) r->name_ptrs[i] = r->name_blob.c_str() + r->name_off[i];

@@ -103,7 +103,7 @@ for sub, extra, env, outp in configs:
 if os.environ.get("KR_TIME_CLI_TRACE"):
     import collections, csv, glob, re, statistics
     td = os.path.join(work, "trace")
-    env = dict(os.environ, TMPDIR="/tmp", GPU_MAX_HW_QUEUES="8")
+    env = dict(os.environ, TMPDIR="/tmp", GPU_MAX_HW_QUEUES="8", KR_CLI_CLEAN_EXIT="1")  # (the tool writes its files when the process exits in order)
     r = subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", td, "--", exe, "dist", "-i", idx, "-q", fq, "-o", out_file],
                        capture_output=True, text=True, env=env)
     d = collections.defaultdict(list)

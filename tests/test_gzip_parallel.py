@@ -219,3 +219,25 @@ def test_block_gzipped_runs_come_with_their_records(capi, tmp_path, par_env):
             got = capi.read_fastx(str(bg), min_bases=100000, stats=st)
             assert _same(got, want), (key, threads, st)
             assert st["gzip_chunks"]["parsed"] >= 3, (key, st)
+
+
+def test_a_stream_that_inflates_beyond_the_memory_bound_is_an_error_that_names_the_streaming_reader(capi, tmp_path, par_env):
+    """deflate allows a thousandfold, and `depth` chunks are in flight: beyond 1 GB out of one 4 MB chunk the parallel reader gives
+    up with a message that names KR_PGZ=0 (zlib's gzread, constant memory) instead of being killed for its memory.  Here with the
+    bound lowered to 1 MB on an ordinary file."""
+    import gzip
+    rng = np.random.default_rng(3)
+    recs = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, rng.choice(np.frombuffer(b"ACGT", np.uint8), 150).tobytes(), b"I" * 150) for i in range(40_000))
+    p = tmp_path / "dense.fq.gz"
+    p.write_bytes(gzip.compress(recs, 6))
+    os.environ["KR_PGZ_MAX_OUT"] = "100000"
+    try:
+        with pytest.raises(capi.KrError) as e:
+            capi.read_fastx(str(p), min_bases=1 << 20)
+        assert e.value.code == capi.KR_ERR_IO and "KR_PGZ=0" in str(e.value)
+        os.environ["KR_PGZ"] = "0"
+        n, b, o = capi.read_fastx(str(p), min_bases=1 << 20)
+        assert len(n) == 40_000 and n[-1] == "r39999"
+    finally:
+        os.environ.pop("KR_PGZ_MAX_OUT", None)
+        os.environ.pop("KR_PGZ", None)
