@@ -175,6 +175,7 @@ struct PlaceDeviceResult { // page-locked host arrays owned by the stream, valid
   const uint32_t* c_se = nullptr;    // per KEPT candidate (chi-square below --chisq, not the root; a read's in emission order):
                                      // placement-tree node, d_llh, v_llh, chi-square
   const double *c_d = nullptr, *c_v = nullptr, *c_chisq = nullptr;
+  uint64_t kept = 0;                 // kept candidates of this range (the next range's go behind them in the host arrays)
   bool overflow = false;             // the device ran out of candidate slots: take the host path for the batch
   uint32_t heavy_reads = 0;          // reads beyond the LDS arrays of kr_place_kernel, done by its second launch (upper bound)
 };
@@ -186,6 +187,14 @@ namespace kr {
 // chi-square of every candidate against the read's closest leaf, all on the device.
 int place_on_device(kr_stream* s, const void* tree_tag, const PlaceTreeArrays& T, const uint32_t* read_len, uint32_t tau,
                     bool no_filter, double chisq, PlaceDeviceResult* out);
+// The same by ranges of reads (round 5): begin once per batch (waits for the front end, sizes the workspaces), then per range
+// launch (asynchronous) and finish (waits, copies the range's results back; `kept_base` = candidates earlier ranges left in the
+// host arrays) -- the host's last phase of one range runs beside the kernels of the next (kr_place_stream).
+int place_device_begin(kr_stream* s, const void* tree_tag, const PlaceTreeArrays& T, const uint32_t* read_len);
+int place_device_launch(kr_stream* s, const PlaceTreeArrays& T, uint32_t r0, uint32_t n, uint32_t tau, bool no_filter, double chisq);
+int place_device_finish(kr_stream* s, const PlaceTreeArrays& T, uint32_t r0, uint32_t n, uint32_t tau, bool no_filter, double chisq,
+                        uint64_t kept_base, PlaceDeviceResult* out);
+uint32_t place_stream_nreads(const kr_stream* s);
 
 } // namespace kr
 

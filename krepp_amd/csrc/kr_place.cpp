@@ -391,8 +391,8 @@ struct CandLite { // what the last phase needs of a candidate
 template <typename Source>
 int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
                     const char* const* names, const kr_params* p, int tabular, int* has_previous, char** text, uint64_t* len,
-                    kr_placement** placements, uint64_t* nplacements, const std::function<void(const char*)>& lap)
-{
+                    kr_placement** placements, uint64_t* nplacements, const std::function<void(const char*)>& lap, uint32_t r_begin = 0)
+{ // reads [r_begin, r_begin + nreads) of the batch (a range of it: kr_place_stream works through a batch in ranges)
   const int nt = std::max(1, std::min(std::min(kr::parallel_width(), 32), (int)(nreads / 4096)));
   auto en = [&](uint32_t q) { return q - 1; };
   auto mid = [&](uint32_t q) { return std::isnan(pt->t.nodes[q].blen) ? 0.0 : pt->t.nodes[q].blen / 2.0; };
@@ -437,7 +437,7 @@ int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
   std::vector<std::string> part((size_t)nt);
   std::vector<std::vector<kr_placement>> ppls((size_t)nt);
   kr::parallel_for(nt, [&](int t) {
-    const uint32_t ra = (uint32_t)((uint64_t)nreads * t / nt), rb = (uint32_t)((uint64_t)nreads * (t + 1) / nt);
+    const uint32_t ra = r_begin + (uint32_t)((uint64_t)nreads * t / nt), rb = r_begin + (uint32_t)((uint64_t)nreads * (t + 1) / nt);
     std::string& out = part[(size_t)t];
     std::vector<kr_placement>& pls = ppls[(size_t)t];
     bool prev = false; // within the piece; pieces are joined with the separator below
@@ -844,31 +844,98 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
   kr::PlaceTreeArrays T;
   T.pn = pt->t.nnodes(), T.nidx = (uint32_t)pt->idx_to_pt.size() - 1;
   T.parent = pt->parent_arr.data(), T.eff = pt->eff.data(), T.elig = pt->elig.data(), T.lo = pt->lo.data(), T.idx_to_pt = pt->idx_to_pt.data(), T.depth = pt->depth.data();
-  kr::PlaceDeviceResult res;
-  int rc = kr::place_on_device(s, pt, T, read_len.data(), p->tau, p->no_filter != 0, p->chisq, &res);
+  // The batch in RANGES of reads (round 5): while the host filters and formats the candidates of one range ("D", as long as the
+  // device's part: 12-17 ms against 12 ms per 400,000 reads on a 1000-genome tree), the place kernels of the next are running.
+  // KR_PLACE_RANGES=1: the whole batch at once, as before.
+  uint32_t nranges = nreads >= 65536u ? 4u : (nreads >= 16384u ? 2u : 1u);
+  if (const char* e = getenv("KR_PLACE_RANGES")) nranges = (uint32_t)std::max(1, std::min(16, atoi(e)));
+  nranges = std::min<uint32_t>(nranges, std::max<uint32_t>(1u, nreads));
+  int rc = kr::place_device_begin(s, pt, T, read_len.data());
   if (rc) return rc;
-  if (res.nreads != nreads) return kr::fail(KR_ERR_ARG, "kr_place_stream: nreads does not match the submitted batch");
-  lap("A-C: aggregation, Brent, chi-square on the device + copy back");
-  if (res.overflow) return host_path();
-  g_place_device_batches.fetch_add(1, std::memory_order_relaxed);
-  g_place_heavy_reads.fetch_add(res.heavy_reads, std::memory_order_relaxed);
-  // each read's candidates in ascending node number (the order the host path forms them in), straight from the
-  // arrays the device wrote
-  struct DeviceSource {
-    const kr::PlaceDeviceResult& res;
-    bool reported(uint32_t r) const { return (res.rd_info[r] >> 31) != 0; }
-    bool single(uint32_t r) const { return ((res.rd_info[r] >> 30) & 1u) != 0; }
-    size_t fetch(uint32_t r, std::vector<CandLite>& buf) const
-    {
-      const uint32_t n = res.rd_info[r] & 0x3FFFFFFFu, c0 = res.rd_c0[r];
-      buf.clear();
-      for (uint32_t i = 0; i < n; ++i) // (0x7FFFFFFF: node 0 of a single placement -- 0 itself marks an unused slot on the device)
-        buf.push_back(CandLite{res.c_se[c0 + i] == 0x7FFFFFFFu ? 0u : res.c_se[c0 + i], res.c_d[c0 + i], res.c_v[c0 + i], res.c_chisq[c0 + i], 1.0});
-      if (n > 1) std::sort(buf.begin(), buf.end(), [](const CandLite& a, const CandLite& b) { return a.se < b.se; });
-      return n;
+  if (kr::place_stream_nreads(s) != nreads) return kr::fail(KR_ERR_ARG, "kr_place_stream: nreads does not match the submitted batch");
+  auto r_of = [&](uint32_t k) { return (uint32_t)((uint64_t)nreads * k / nranges); };
+  lap("front end waited for, workspaces");
+  if ((rc = kr::place_device_launch(s, T, 0, r_of(1), p->tau, p->no_filter != 0, p->chisq))) return rc;
+  struct Piece { char* text = nullptr; uint64_t len = 0; kr_placement* pl = nullptr; uint64_t npl = 0; };
+  std::vector<Piece> pieces(nranges);
+  auto drop = [&]() {
+    for (auto& pc : pieces) free(pc.text), free(pc.pl);
+  };
+  uint64_t kept_base = 0, heavy = 0;
+  int prev = *has_previous;
+  bool overflow = false;
+  for (uint32_t k = 0; k < nranges && !rc; ++k) {
+    const uint32_t r0 = r_of(k), r1 = r_of(k + 1);
+    kr::PlaceDeviceResult res;
+    rc = kr::place_device_finish(s, T, r0, r1 - r0, p->tau, p->no_filter != 0, p->chisq, kept_base, &res);
+    if (rc) break;
+    lap("A-C of a range: aggregation, Brent, chi-square on the device + copy back");
+    if (res.overflow) {
+      overflow = true;
+      break;
     }
-  } src{res};
-  return emit_placements(pt, nreads, src, names, p, tabular, has_previous, text, len, placements, nplacements, lap);
+    heavy += res.heavy_reads;
+    kept_base += res.kept;
+    if (k + 1 < nranges) // the next range's kernels run beside this range's last phase
+      if ((rc = kr::place_device_launch(s, T, r1, r_of(k + 2) - r1, p->tau, p->no_filter != 0, p->chisq))) break;
+    // each read's candidates in ascending node number (the order the host path forms them in), straight from the
+    // arrays the device wrote
+    struct DeviceSource {
+      const kr::PlaceDeviceResult& res;
+      bool reported(uint32_t r) const { return (res.rd_info[r] >> 31) != 0; }
+      bool single(uint32_t r) const { return ((res.rd_info[r] >> 30) & 1u) != 0; }
+      size_t fetch(uint32_t r, std::vector<CandLite>& buf) const
+      {
+        const uint32_t n = res.rd_info[r] & 0x3FFFFFFFu, c0 = res.rd_c0[r];
+        buf.clear();
+        for (uint32_t i = 0; i < n; ++i) // (0x7FFFFFFF: node 0 of a single placement -- 0 itself marks an unused slot on the device)
+          buf.push_back(CandLite{res.c_se[c0 + i] == 0x7FFFFFFFu ? 0u : res.c_se[c0 + i], res.c_d[c0 + i], res.c_v[c0 + i], res.c_chisq[c0 + i], 1.0});
+        if (n > 1) std::sort(buf.begin(), buf.end(), [](const CandLite& a, const CandLite& b) { return a.se < b.se; });
+        return n;
+      }
+    } src{res};
+    Piece& pc = pieces[k];
+    rc = emit_placements(pt, r1 - r0, src, names, p, tabular, &prev, &pc.text, &pc.len, placements ? &pc.pl : nullptr, nplacements ? &pc.npl : nullptr, lap, r0);
+  }
+  if (rc) {
+    drop();
+    (void)kr_batch_wait(s); // (whatever was queued runs to its end before the stream is used again)
+    return rc;
+  }
+  if (overflow) { // out of candidate slots beyond what a rerun can name: the host back end takes the whole batch
+    drop();
+    return host_path();
+  }
+  g_place_device_batches.fetch_add(1, std::memory_order_relaxed);
+  g_place_heavy_reads.fetch_add(heavy, std::memory_order_relaxed);
+  // the ranges' pieces joined in order
+  if (nranges == 1) {
+    *text = pieces[0].text, *len = pieces[0].len;
+    if (placements && nplacements) *placements = pieces[0].pl, *nplacements = pieces[0].npl;
+  } else {
+    uint64_t tl = 0, tp = 0;
+    for (auto& pc : pieces) tl += pc.len, tp += pc.npl;
+    char* buf = (char*)malloc(tl + 1);
+    kr_placement* pb = (placements && nplacements) ? (kr_placement*)malloc(std::max<uint64_t>(1, tp) * sizeof(kr_placement)) : nullptr;
+    if (!buf || ((placements && nplacements) && !pb)) {
+      free(buf), free(pb);
+      drop();
+      return kr::fail(KR_ERR_NOMEM, "kr_place_stream: out of memory");
+    }
+    std::vector<uint64_t> at(nranges + 1, 0), pat(nranges + 1, 0);
+    for (uint32_t k = 0; k < nranges; ++k) at[k + 1] = at[k] + pieces[k].len, pat[k + 1] = pat[k] + pieces[k].npl;
+    kr::parallel_for((int)nranges, [&](int k) {
+      if (pieces[(size_t)k].len) memcpy(buf + at[(size_t)k], pieces[(size_t)k].text, pieces[(size_t)k].len);
+      if (pb && pieces[(size_t)k].npl) memcpy(pb + pat[(size_t)k], pieces[(size_t)k].pl, pieces[(size_t)k].npl * sizeof(kr_placement));
+    });
+    buf[tl] = 0;
+    drop();
+    *text = buf, *len = tl;
+    if (pb) *placements = pb, *nplacements = tp;
+    lap("ranges joined");
+  }
+  *has_previous = prev;
+  return KR_OK;
 }
 
 void kr_place_counters(uint64_t* device_batches, uint64_t* host_batches, uint64_t* heavy_reads)

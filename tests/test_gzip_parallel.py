@@ -241,3 +241,31 @@ def test_a_stream_that_inflates_beyond_the_memory_bound_is_an_error_that_names_t
     finally:
         os.environ.pop("KR_PGZ_MAX_OUT", None)
         os.environ.pop("KR_PGZ", None)
+
+
+def test_header_crc_is_checked_like_zlib_checks_it(capi, tmp_path, par_env):
+    """a member header with the FHCRC flag: right, the records come out of either reader; wrong, both refuse the file (zlib's
+    inflate reports "header crc mismatch"; the parallel reader verified nothing there until round 5)"""
+    import struct
+    import zlib
+    recs = b"".join(b"@r%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(5000))
+
+    def member(data, good):
+        hdr = b"\x1f\x8b\x08\x02" + b"\x00" * 4 + b"\x00\xff"
+        c = (zlib.crc32(hdr) & 0xFFFF) ^ (0 if good else 1)
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        return hdr + struct.pack("<H", c) + co.compress(data) + co.flush() + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data))
+
+    os.environ["KR_PGZ_CHUNK"] = "65536"
+    for good in (True, False):
+        p = tmp_path / f"fh{int(good)}.fq.gz"
+        p.write_bytes(member(recs, good))
+        for pgz in ("1", "0"):
+            os.environ["KR_PGZ"] = pgz
+            if good:
+                n, b, o = capi.read_fastx(str(p), min_bases=1 << 16)
+                assert len(n) == 5000 and n[-1] == "r4999"
+            else:
+                with pytest.raises(capi.KrError) as e:
+                    capi.read_fastx(str(p), min_bases=1 << 16)
+                assert e.value.code == capi.KR_ERR_IO

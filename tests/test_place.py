@@ -285,6 +285,34 @@ def test_device_back_end_equals_host_back_end(capi, po, toy_index_dir, toy_reads
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ranges", ["1", "2", "3", "16"])
+def test_ranges_of_a_batch_give_the_batch_s_output(capi, po, toy_index_dir, toy_reads, toy_genomes, synth, monkeypatch, ranges):
+    """kr_place_stream works through a batch in ranges of reads (the host's last phase of one range beside the place kernels of the
+    next, round 5): whatever the number of ranges (KR_PLACE_RANGES; 4 by default from 65,536 reads), text -- jplace separators
+    included --, placements and summary equal the host back end's, also when every read of a range exceeds the LDS limits and
+    when the candidate slots run out and a range is run again."""
+    b2, o2, n2 = synth.sample_reads(toy_genomes, 20_000, seed=29)
+    hx = capi.HostIndex(toy_index_dir)
+    for env in (dict(), dict(KR_DEBUG_PLACE_LDS="3,8")):
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        for tabular in (0, 1, 2):
+            ref = None
+            for host in (True, False):
+                monkeypatch.setenv("KR_PLACE_RANGES", ranges)
+                pl = capi.Placer(hx, None, 0, tabular=tabular, max_reads=len(n2), max_bases=len(b2))
+                text, p = pl.place(b2, o2, n2, host=host)
+                got = (text, p.tobytes(), pl.summary() if tabular == 2 else "")
+                pl.close()
+                if ref is None:
+                    ref = got
+                assert got == ref, (ranges, tabular, env)
+            assert len(ref[1]) > 0
+        for k_ in env:
+            monkeypatch.delenv(k_)
+
+
+@pytest.mark.gpu
 def test_large_batch_goes_through_the_thread_pool(capi, po, toy_index_dir, toy_reads):
     """Batches of more than 8,192 reads are cut into ranges handled by several host threads (kr::parallel_for):
     aggregation, candidate lists, text pieces and the jplace separators must come out as for one thread."""
