@@ -846,8 +846,10 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
   T.parent = pt->parent_arr.data(), T.eff = pt->eff.data(), T.elig = pt->elig.data(), T.lo = pt->lo.data(), T.idx_to_pt = pt->idx_to_pt.data(), T.depth = pt->depth.data();
   // The batch in RANGES of reads (round 5): while the host filters and formats the candidates of one range ("D", as long as the
   // device's part: 12-17 ms against 12 ms per 400,000 reads on a 1000-genome tree), the place kernels of the next are running.
-  // KR_PLACE_RANGES=1: the whole batch at once, as before.
-  uint32_t nranges = nreads >= 65536u ? 4u : (nreads >= 16384u ? 2u : 1u);
+  // Two ranges from 131,072 reads (400,000 reads, tabular, one call at a time: 8.0 M reads/s whole, 12.8 M in two ranges, 10.0 M in
+  // four, 9.2 M in eight -- every range has its own launches, waits and copies; a 65,536-read batch of the CLI loses in any split:
+  // profiles/round5_place_ranges.txt).  KR_PLACE_RANGES=1: the whole batch at once, as before.
+  uint32_t nranges = nreads >= 131072u ? 2u : 1u;
   if (const char* e = getenv("KR_PLACE_RANGES")) nranges = (uint32_t)std::max(1, std::min(16, atoi(e)));
   nranges = std::min<uint32_t>(nranges, std::max<uint32_t>(1u, nreads));
   int rc = kr::place_device_begin(s, pt, T, read_len.data());

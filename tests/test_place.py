@@ -288,7 +288,7 @@ def test_device_back_end_equals_host_back_end(capi, po, toy_index_dir, toy_reads
 @pytest.mark.parametrize("ranges", ["1", "2", "3", "16"])
 def test_ranges_of_a_batch_give_the_batch_s_output(capi, po, toy_index_dir, toy_reads, toy_genomes, synth, monkeypatch, ranges):
     """kr_place_stream works through a batch in ranges of reads (the host's last phase of one range beside the place kernels of the
-    next, round 5): whatever the number of ranges (KR_PLACE_RANGES; 4 by default from 65,536 reads), text -- jplace separators
+    next, round 5): whatever the number of ranges (KR_PLACE_RANGES; 2 by default from 131,072 reads), text -- jplace separators
     included --, placements and summary equal the host back end's, also when every read of a range exceeds the LDS limits and
     when the candidate slots run out and a range is run again."""
     b2, o2, n2 = synth.sample_reads(toy_genomes, 20_000, seed=29)
