@@ -126,6 +126,14 @@ def test_device_text_on_200000_reads_and_its_error_paths(capi, synth, toy_genome
     lt.collect()
     t2 = lt.format_dist(hx, n2)
     assert t2.startswith(want[:50]) and "contig\t" in t2
+    # ... and when the tiles' records "do not fit" (KR_DEBUG_TILE_OVERFLOW: kr_batch_wait runs the batch again, one wave per
+    # sequence) the rerun is still a text batch: the device's bytes, equal to the host formatter's
+    os.environ["KR_DEBUG_TILE_OVERFLOW"] = "1"
+    try:
+        lt.submit_text(b2, o2, n2)
+        assert lt.collect_text().decode() == t2
+    finally:
+        del os.environ["KR_DEBUG_TILE_OVERFLOW"]
     lt.close()
     dx.close()
     hx.close()
