@@ -256,3 +256,36 @@ d=json.loads([l for l in open('gpurun_out/r5_s14_bench_driver.json') if l.starts
 print(round(d['value']/1e6,2), round(d['ms_per_step'],2), d['kernel_ms']['scan'], d['kernel_ms']['accumulate'], d['kernel_ms']['llh_select'], 'frac', round(d['roofline']['frac'],3), d['roofline']['frac_traffic'], 'host', round(h['value']/1e6,2), round(h['steady_state']['value']/1e6,2), d['check']['rows_equal'], d['cpu_baseline']['value'])"
 python scripts/time_cli.py 16000000 2>&1 | grep "elapsed" | grep -o "^[a-z]* \[[^]]*\] {[^}]*}\|elapsed: [0-9.]* sec ([0-9]* reads/s" | paste - - | head -12
 KR_TIME_CLI_CONFIGS=0,6,7,8 python scripts/time_cli_syn1000.py 8e6 2>&1 | grep "rc 0" | cut -c1-200
+# round 5, session 15: the straight-line epilogue with counts instead of planes -- parity, then A/B by kernel time on both indexes
+ulimit -c 0
+mkdir -p gpurun_out
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_text.py tests/test_gpu_long_sequences.py tests/test_gpu_filter_slots.py tests/test_gpu_syn1000.py::test_ten_thousand_genome_index_vs_oracle -x -q > gpurun_out/r5_s15_tests.txt 2>&1
+grep -n "passed\|failed" gpurun_out/r5_s15_tests.txt; tail -3 gpurun_out/r5_s15_tests.txt | cut -c1-200
+cp krepp_amd/lib/libkrepp_amd.so /tmp/main_lib.so
+for w in syn1000 syn10000; do
+  bash scripts/ktimes.sh ${w}_main --workload $w > gpurun_out/r5_s15_ktimes_${w}_counts.txt 2>&1
+  echo "== $w counts"; grep "acc_kernel_t<true, 5, false, 7\|scan_pipe" gpurun_out/r5_s15_ktimes_${w}_counts.txt
+  cp krepp_amd/lib/variants/planes/libkrepp_amd.so krepp_amd/lib/libkrepp_amd.so
+  bash scripts/ktimes.sh ${w}_planes --workload $w > gpurun_out/r5_s15_ktimes_${w}_planes.txt 2>&1
+  echo "== $w planes"; grep "acc_kernel_t<true, 5, false, 7\|scan_pipe" gpurun_out/r5_s15_ktimes_${w}_planes.txt
+  cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so
+done
+cp krepp_amd/lib/variants/stats/libkrepp_amd.so krepp_amd/lib/libkrepp_amd.so
+S="--no-cpu-baseline --no-host-inclusive --steps 1 --warmup 0 --check-reads 1000 --skip-host-path-check --distinct-batches 1"
+for w in syn1000 syn10000; do KR_ITEM_PLACEMENT_TRIALS=0 KR_DEBUG_SKIP=512 python bench.py --workload $w $S 2>&1 | grep "kr stats\] paths\|kr stats\] reads [0-9]" | cut -c1-330; done
+cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so
+# round 5, session 16: HEAD after the count epilogue -- the whole GPU suite, the profile set again (stage digests), bench lines
+TAG=r5b
+ulimit -c 0
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_tests.txt 2>&1
+grep -n "passed\|failed\|error" gpurun_out/${TAG}_tests.txt | head -3
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+bash scripts/profile.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1
+python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+python3 scripts/traffic.py gpurun_out/prof_$TAG gpurun_out/${TAG}_bench.json gpurun_out/${TAG}_traffic.json > gpurun_out/${TAG}_traffic.log 2>&1
+cp gpurun_out/${TAG}_traffic.json profiles/traffic_latest.json
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver.json 2> gpurun_out/${TAG}_bench_driver.err
+tail -c 300 gpurun_out/${TAG}_bench_driver.json
+python3 bench.py --workload syn10000 --no-cpu-baseline > gpurun_out/${TAG}_s10k_bench.json 2> gpurun_out/${TAG}_s10k_bench.err
+tail -c 200 gpurun_out/${TAG}_s10k_bench.json
