@@ -342,3 +342,155 @@ for w in syn1000 syn10000; do
   done
   cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so
 done
+# round 5, session 20: events of spilled reads compacted into the LDS (KR_ACC_COMPACT_SPILLED): parity, then the accumulate kernel's time
+# with and without on both indexes
+ulimit -c 0
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_text.py tests/test_gpu_long_sequences.py tests/test_gpu_filter_slots.py \
+  tests/test_gpu_syn1000.py tests/test_gpu_place_k27.py -x -q -m gpu > gpurun_out/r5_s20_tests.txt 2>&1
+tail -3 gpurun_out/r5_s20_tests.txt
+cp krepp_amd/lib/libkrepp_amd.so /tmp/main_lib.so
+for w in syn1000 syn10000; do
+  bash scripts/ktimes.sh ${w}_compact --workload $w > gpurun_out/r5_s20_${w}_compact.txt 2>&1
+  echo "== $w compacted"; grep "acc_kernel_t<true, 5, false, 7\|sum of max" gpurun_out/r5_s20_${w}_compact.txt
+  cp krepp_amd/lib/variants/nocompact/libkrepp_amd.so krepp_amd/lib/libkrepp_amd.so
+  bash scripts/ktimes.sh ${w}_nocompact --workload $w > gpurun_out/r5_s20_${w}_nocompact.txt 2>&1
+  echo "== $w not compacted"; grep "acc_kernel_t<true, 5, false, 7\|sum of max" gpurun_out/r5_s20_${w}_nocompact.txt
+  cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so
+done
+python bench.py > gpurun_out/r5_s20_bench.json 2> gpurun_out/r5_s20_bench.err; cat gpurun_out/r5_s20_bench.json | cut -c1-400
+# round 5, session 21: straight-line epilogue with key batches and exact handling of a position hit twice, spilled reads compacted up to
+# 768 live events: parity (whole suite), then the accumulate kernel's time with and without the compaction
+ulimit -c 0
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_long_sequences.py tests/test_gpu_syn1000.py -x -q -m gpu > gpurun_out/r5_s21_tests.txt 2>&1
+tail -3 gpurun_out/r5_s21_tests.txt
+cp krepp_amd/lib/libkrepp_amd.so /tmp/main_lib.so
+for w in syn1000 syn10000; do
+  bash scripts/ktimes.sh ${w}_compact --workload $w > gpurun_out/r5_s21_${w}_compact.txt 2>&1
+  echo "== $w compacted"; grep "acc_kernel_t<true, 5, false, 7\|sum of max" gpurun_out/r5_s21_${w}_compact.txt
+  cp krepp_amd/lib/variants/nocompact/libkrepp_amd.so krepp_amd/lib/libkrepp_amd.so
+  bash scripts/ktimes.sh ${w}_nocompact --workload $w > gpurun_out/r5_s21_${w}_nocompact.txt 2>&1
+  echo "== $w not compacted"; grep "acc_kernel_t<true, 5, false, 7\|sum of max" gpurun_out/r5_s21_${w}_nocompact.txt
+  cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so
+done
+python bench.py > gpurun_out/r5_s21_bench.json 2> gpurun_out/r5_s21_bench.err; cut -c1-300 gpurun_out/r5_s21_bench.json
+python bench.py --workload syn10000 --no-cpu-baseline > gpurun_out/r5_s21_bench_syn10000.json 2> gpurun_out/r5_s21_bench_syn10000.err; cut -c1-300 gpurun_out/r5_s21_bench_syn10000.json
+timeout 1200 python -m pytest tests/ -x -q -m gpu --deselect tests/test_gpu_parity.py --deselect tests/test_gpu_long_sequences.py --deselect tests/test_gpu_syn1000.py > gpurun_out/r5_s21_tests2.txt 2>&1
+tail -3 gpurun_out/r5_s21_tests2.txt
+# round 5, session 22: in-place compaction for reads whose keys do not fit one batch; the LDS event capacity at 768 and 1024 instead of 512;
+# what the reads with spilled events still cost (scripts/acc_spilled_reads_ablation.diff: 8 = such a read does nothing after its events
+# are collected, 9 = nothing after the compaction)
+ulimit -c 0
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_syn1000.py::test_ten_thousand_genome_index_vs_oracle -x -q -m gpu > gpurun_out/r5_s22_tests.txt 2>&1
+tail -3 gpurun_out/r5_s22_tests.txt
+cp krepp_amd/lib/libkrepp_amd.so /tmp/main_lib.so
+for w in syn1000 syn10000; do
+  for v in main ev768 ev1024 abl8 abl9; do
+    if [ $w = syn10000 ] && [ ${v#abl} != $v ]; then continue; fi
+    if [ $v = main ]; then cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so; else cp krepp_amd/lib/variants/$v/libkrepp_amd.so krepp_amd/lib/libkrepp_amd.so; fi
+    bash scripts/ktimes.sh ${w}_$v --workload $w > gpurun_out/r5_s22_${w}_$v.txt 2>&1
+    echo "== $w $v"; grep "acc_kernel_t<true, 5, false, 7\|sum of max" gpurun_out/r5_s22_${w}_$v.txt
+  done
+done
+cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so
+# round 5, session 23: 1,024 events in the LDS, one compaction pass (what does not fit goes back to the global scratch), spilled tiles loaded
+# four at a time; parity, then what is left (scripts/acc_spilled_reads_ablation.diff: 8 = a read with spilled events does nothing after its
+# events are collected, 9 = nothing after the compaction, 10 = no read does anything after marks / compaction)
+ulimit -c 0
+mkdir -p gpurun_out
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_syn1000.py tests/test_gpu_long_sequences.py -x -q -m gpu > gpurun_out/r5_s23_tests.txt 2>&1
+tail -3 gpurun_out/r5_s23_tests.txt
+cp krepp_amd/lib/libkrepp_amd.so /tmp/main_lib.so
+for w in syn1000 syn10000; do
+  for v in main abl8 abl9 abl10; do
+    if [ $v = main ]; then cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so; else cp krepp_amd/lib/variants/$v/libkrepp_amd.so krepp_amd/lib/libkrepp_amd.so; fi
+    bash scripts/ktimes.sh ${w}_$v --workload $w > gpurun_out/r5_s23_${w}_$v.txt 2>&1
+    echo "== $w $v"; grep "acc_kernel_t<true, 5, false, 7\|sum of max" gpurun_out/r5_s23_${w}_$v.txt
+  done
+done
+cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so
+# round 5, session 24: HEAD after the epilogue work of sessions 20-23 -- the whole GPU suite, smoke, the profile set, bench lines
+TAG=r5c
+ulimit -c 0
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_tests.txt 2>&1
+grep -n "passed\|failed\|error" gpurun_out/${TAG}_tests.txt | head -3
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+bash scripts/profile.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1
+python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+python3 scripts/traffic.py gpurun_out/prof_$TAG gpurun_out/${TAG}_bench.json gpurun_out/${TAG}_traffic.json > gpurun_out/${TAG}_traffic.log 2>&1
+cp gpurun_out/${TAG}_traffic.json profiles/traffic_latest.json
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver.json 2> gpurun_out/${TAG}_bench_driver.err
+tail -c 300 gpurun_out/${TAG}_bench_driver.json
+python3 bench.py --workload syn10000 --no-cpu-baseline > gpurun_out/${TAG}_s10k_bench.json 2> gpurun_out/${TAG}_s10k_bench.err
+tail -c 200 gpurun_out/${TAG}_s10k_bench.json
+# round 5, session 25: reads whose live events do not fit the LDS finished from position maps and counters in the wave's global scratch
+# (finish_big_read) instead of finalize_events' global planes: parity (also with every key of such a read counted again from the events:
+# the path a position hit twice takes), then the accumulate kernel with and without
+ulimit -c 0
+mkdir -p gpurun_out
+BIG="tests/test_gpu_parity.py::test_large_clade_colours_spill_the_work_stack tests/test_gpu_parity.py::test_forty_thousand_leaves tests/test_gpu_parity.py::test_many_leaves_bitmap_spans_several_tiles tests/test_gpu_parity.py::test_single_segment_many_leaves_spill_paths tests/test_gpu_parity.py::test_overflow_path_many_leaves tests/test_gpu_parity.py::test_crafted_min_rule_null_nodes_and_th tests/test_gpu_syn1000.py::test_ten_thousand_genome_index_vs_oracle"
+cp krepp_amd/lib/libkrepp_amd.so /tmp/main_lib.so
+cp krepp_amd/lib/variants/recount/libkrepp_amd.so krepp_amd/lib/libkrepp_amd.so
+timeout 900 python -m pytest $BIG -x -q -m gpu > gpurun_out/r5_s25_tests_recount.txt 2>&1
+echo "== every key counted again:"; tail -3 gpurun_out/r5_s25_tests_recount.txt | cut -c1-300
+cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_syn1000.py tests/test_gpu_long_sequences.py -x -q -m gpu > gpurun_out/r5_s25_tests.txt 2>&1
+tail -3 gpurun_out/r5_s25_tests.txt | cut -c1-300
+for w in syn10000 syn1000; do
+  for v in main nobig; do
+    if [ $v = main ]; then cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so; else cp krepp_amd/lib/variants/$v/libkrepp_amd.so krepp_amd/lib/libkrepp_amd.so; fi
+    bash scripts/ktimes.sh ${w}_$v --workload $w > gpurun_out/r5_s25_${w}_$v.txt 2>&1
+    echo "== $w $v"; grep "acc_kernel_t<true, 5, false, 7\|sum of max" gpurun_out/r5_s25_${w}_$v.txt
+  done
+done
+cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so
+# round 5, session 26: finish_big_read as a function of its own (inlined it cost the 1000-genome index 2.8 ms: session 25) -- the tests with
+# big reads (also with every key counted again), the accumulate kernel with and without
+ulimit -c 0
+mkdir -p gpurun_out
+BIG="tests/test_gpu_parity.py::test_large_clade_colours_spill_the_work_stack tests/test_gpu_parity.py::test_forty_thousand_leaves tests/test_gpu_parity.py::test_many_leaves_bitmap_spans_several_tiles tests/test_gpu_parity.py::test_single_segment_many_leaves_spill_paths tests/test_gpu_parity.py::test_overflow_path_many_leaves tests/test_gpu_parity.py::test_crafted_min_rule_null_nodes_and_th tests/test_gpu_syn1000.py::test_ten_thousand_genome_index_vs_oracle"
+cp krepp_amd/lib/libkrepp_amd.so /tmp/main_lib.so
+cp krepp_amd/lib/variants/recount/libkrepp_amd.so krepp_amd/lib/libkrepp_amd.so
+timeout 900 python -m pytest $BIG -x -q -m gpu > gpurun_out/r5_s26_tests_recount.txt 2>&1
+echo "== every key counted again:"; tail -3 gpurun_out/r5_s26_tests_recount.txt | cut -c1-300
+cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so
+timeout 900 python -m pytest $BIG -x -q -m gpu > gpurun_out/r5_s26_tests.txt 2>&1
+tail -3 gpurun_out/r5_s26_tests.txt | cut -c1-300
+for w in syn1000 syn10000; do
+  for v in main nobig; do
+    if [ $v = main ]; then cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so; else cp krepp_amd/lib/variants/$v/libkrepp_amd.so krepp_amd/lib/libkrepp_amd.so; fi
+    bash scripts/ktimes.sh ${w}_$v --workload $w > gpurun_out/r5_s26_${w}_$v.txt 2>&1
+    echo "== $w $v"; grep "acc_kernel_t<true, 5, false, 7\|sum of max" gpurun_out/r5_s26_${w}_$v.txt
+  done
+done
+cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so
+# round 5, session 27: finish_big_read only for reads whose live events overflow the LDS (session 26: the reads that merely fill it are
+# faster in finalize_events) -- the tests with big reads, the accumulate kernel on both indexes
+ulimit -c 0
+mkdir -p gpurun_out
+BIG="tests/test_gpu_parity.py::test_large_clade_colours_spill_the_work_stack tests/test_gpu_parity.py::test_forty_thousand_leaves tests/test_gpu_parity.py::test_many_leaves_bitmap_spans_several_tiles tests/test_gpu_parity.py::test_single_segment_many_leaves_spill_paths tests/test_gpu_parity.py::test_crafted_min_rule_null_nodes_and_th tests/test_gpu_syn1000.py::test_ten_thousand_genome_index_vs_oracle"
+timeout 900 python -m pytest $BIG -x -q -m gpu > gpurun_out/r5_s27_tests.txt 2>&1
+tail -3 gpurun_out/r5_s27_tests.txt | cut -c1-300
+for w in syn1000 syn10000; do
+  bash scripts/ktimes.sh ${w}_main --workload $w > gpurun_out/r5_s27_${w}_main.txt 2>&1
+  echo "== $w main"; grep "acc_kernel_t<true, 5, false, 7\|sum of max" gpurun_out/r5_s27_${w}_main.txt
+done
+# round 5, session 28: finish_big_read with planes in the global scratch and no returning atomic -- the tests with big reads, the accumulate
+# kernel on both indexes with and without
+ulimit -c 0
+mkdir -p gpurun_out
+BIG="tests/test_gpu_parity.py::test_large_clade_colours_spill_the_work_stack tests/test_gpu_parity.py::test_forty_thousand_leaves tests/test_gpu_parity.py::test_many_leaves_bitmap_spans_several_tiles tests/test_gpu_parity.py::test_single_segment_many_leaves_spill_paths tests/test_gpu_parity.py::test_crafted_min_rule_null_nodes_and_th tests/test_gpu_syn1000.py::test_ten_thousand_genome_index_vs_oracle"
+timeout 900 python -m pytest $BIG -x -q -m gpu > gpurun_out/r5_s28_tests.txt 2>&1
+tail -3 gpurun_out/r5_s28_tests.txt | cut -c1-300
+cp krepp_amd/lib/libkrepp_amd.so /tmp/main_lib.so
+for w in syn1000 syn10000; do
+  for v in main nobig; do
+    if [ $v = main ]; then cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so; else cp krepp_amd/lib/variants/$v/libkrepp_amd.so krepp_amd/lib/libkrepp_amd.so; fi
+    bash scripts/ktimes.sh ${w}_$v --workload $w > gpurun_out/r5_s28_${w}_$v.txt 2>&1
+    echo "== $w $v"; grep "acc_kernel_t<true, 5, false, 7\|sum of max" gpurun_out/r5_s28_${w}_$v.txt
+  done
+done
+cp /tmp/main_lib.so krepp_amd/lib/libkrepp_amd.so
