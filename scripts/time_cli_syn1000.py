@@ -84,6 +84,11 @@ configs = [
 if os.environ.get("KR_TIME_CLI_CONFIGS"):  # e.g. "0,5,7"
     configs = [configs[int(i)] for i in os.environ["KR_TIME_CLI_CONFIGS"].split(",")]
 for sub, extra, env, outp in configs:
+    # a fresh output file every time: closing a file that was truncated and rewritten makes ext4 allocate its blocks at close()
+    # (0.6 s for 6 GB, inside the CLI's elapsed time as inside the reference's) -- every configuration after the first paid that
+    # in the earlier runs of this script (profiles/round5_cli_syn1000.txt: the gap between a worker's last batch and `elapsed`)
+    if outp != "/dev/null" and os.path.exists(outp):
+        os.remove(outp)
     t = time.time()
     r = subprocess.run([exe, sub, "-i", idx, "-q", fq, "-o", outp] + extra, capture_output=True, text=True, env=dict(os.environ, KR_CLI_TIMING="1", **env))
     dt = time.time() - t
