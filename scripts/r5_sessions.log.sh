@@ -516,3 +516,5 @@ KR_TIME_CLI_CONFIGS=0,2,3,4,1,7,8,0 timeout 400 python scripts/time_cli_syn1000.
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 bash scripts/profile.sh r5e > gpurun_out/r5e_profile.log 2>&1
 python3 scripts/traffic.py gpurun_out/prof_r5e gpurun_out/prof_r5e/bench_trace.log gpurun_out/r5e_traffic.json > gpurun_out/r5e_traffic.log 2>&1
+# round 5, session 33: --no-multi / --summarize with three and four workers, 524,288-read batches
+KR_TIME_CLI_CONFIGS=8,9,10,11,12,8,9 timeout 190 python scripts/time_cli_syn1000.py 8e6 > gpurun_out/r5_s33_cli_syn1000.txt 2>&1

@@ -80,6 +80,10 @@ configs = [
     ("dist", [], {}, "/dev/null"),
     ("dist", ["--summarize"], {}, out_file),
     ("dist", ["--no-multi"], {}, out_file),
+    ("dist", ["--no-multi"], {"KR_CLI_WORKERS_PER_GPU": "3"}, out_file),  # 9
+    ("dist", ["--summarize"], {"KR_CLI_WORKERS_PER_GPU": "3"}, out_file),  # 10
+    ("dist", ["--no-multi"], {"KR_CLI_WORKERS_PER_GPU": "4"}, out_file),  # 11
+    ("dist", ["--no-multi"], {"KR_CLI_BATCH_READS": "524288"}, out_file),  # 12
 ]
 if os.environ.get("KR_TIME_CLI_CONFIGS"):  # e.g. "0,5,7"
     configs = [configs[int(i)] for i in os.environ["KR_TIME_CLI_CONFIGS"].split(",")]
