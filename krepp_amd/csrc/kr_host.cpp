@@ -1544,7 +1544,11 @@ int kr_fastx_next(kr_fastx* r, uint64_t min_bases, kr_fastx_batch* out)
       const bool ramp = c->ramp;
       if (P.spare.size() < 2 * P.depth) P.spare.push_back(std::move(c)); // (with the batch's previous vectors: their capacity serves the next chunk)
       P.issue();
-      if (bpc >= min_bases || ramp) break; // (a short first chunk goes out as the short batch it is: the caller's workers start on it)
+      // One chunk is a batch: a chunk of 2 * min_bases bytes of ordinary FASTQ (2 L + 6 + name bytes per record of L bases) holds about
+      // 0.94 * min_bases bases, and asking for all of min_bases took a second chunk for every steady batch -- appended by copy, and
+      // the batch of 1.9 * min_bases then too large for the CLI to hand over whole (round-5 advice).  (A short first chunk goes
+      // out as the short batch it is: the caller's workers start on it.)
+      if (bpc >= min_bases - min_bases / 8 || ramp) break;
     }
     if (fall_back && resume >= P.size && P.size != 0) {
       // every byte of the file went through the pool: the input is exhausted.  The pool (its threads, and gigabytes of recycled

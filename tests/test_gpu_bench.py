@@ -51,6 +51,10 @@ def test_bench_default_line_small():
     ck = out["check"]
     assert ck["from_timed_launch"] and ck["reads_in_that_launch"] == 200000 and ck["rows_equal"] and ck["max_rel_dist_err"] < 1e-6
     assert ck["host_path_small_stream"]["rows_equal"]
+    # ... and ALL rows of that launch are what a second, independent stream makes of the same batch
+    wl = ck["whole_launch"]
+    assert wl["reads"] == 200000 and wl["rows"] > 200000 and wl["equal_on_an_independent_stream"]
+    assert "--workload syn" not in out["config"]["workload_choice"] and out["setup_parts_s"]["read_procs"] >= 1
     assert out["config"]["item_list_placement"]["finished_before_timing"]
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["value"] > 0
     assert out["check"]["rows_equal"]

@@ -9,7 +9,7 @@ kr_host_index.inc); and KR_SLOT_LOG2W=0, the packed table only -- 20,000 reads a
 (Index.replace_table) — table hits (src/query.cpp:352-368, src/index.cpp:160-168) and histograms (src/query.hpp:153-176)
 bit-exact, DIST within the north star's 1e-6 relative — then a full 1,000,000-read batch through the size-independent
 properties (reverse complement, permutation, split); on the default layout (and on the filter slots) the same three properties
-once more at 4,000,000 reads per launch -- the size class of bench.py's timed launches (item lists of hundreds of millions of
+once more at 8,000,000 reads per launch -- the size of bench.py's timed launches (4,000,000 on the filter slots) (item lists of hundreds of millions of
 entries, every cursor range in use; the byte-table front end, finalize_events_fast, kr_select_lane_kernel and the row compaction
 all on their default paths) -- compared through an order-independent 128-bit checksum of the rows.
 """
@@ -23,7 +23,7 @@ from conftest import assert_rows_close, rows_of_oracle
 pytestmark = pytest.mark.gpu
 
 N_GENOMES, GENOME_LEN, INDEX_GB = 1000, 100_000, 10.0
-N_ORACLE, N_FULL, N_LAUNCH = 20_000, 1_000_000, 4_000_000
+N_ORACLE, N_FULL, N_LAUNCH = 20_000, 1_000_000, 8_000_000  # N_LAUNCH = bench.py's reads per timed launch (format 6; the opt-in filter slots take half)
 
 
 def rows_checksum(read, se, dbits):
@@ -139,10 +139,10 @@ def test_syn1000_10gb_index_vs_oracle_and_full_batch_properties(capi, po, synth,
         monkeypatch.delenv("KR_LANES")
         monkeypatch.delenv("KR_ITEM_PLACEMENT_TRIALS", raising=False)
 
-        # ---- 4,000,000 reads per launch (format 6 = the default layout bench.py times; format 9 = the opt-in filter slots):
-        #      the same properties at the size class of bench.py's timed launches ----
+        # ---- 8,000,000 reads per launch on format 6 (= the default layout and the launch size bench.py times; 4,000,000 on
+        #      format 9, the opt-in filter slots): the same properties at the size of bench.py's timed launches ----
         if slot_log2w in ("6", "9"):
-            n = N_LAUNCH
+            n = N_LAUNCH if slot_log2w == "6" else N_LAUNCH // 2
             bases, offs = make_reads(synth, genomes, n, seed=6)
             stl = dx.stream(max_reads=n, max_bases=len(bases), max_records=n * 64)
 
@@ -157,13 +157,13 @@ def test_syn1000_10gb_index_vs_oracle_and_full_batch_properties(capi, po, synth,
 
             base_sum = run_sum(bases, offs)
             assert base_sum[2] > 20 * n
-            assert run_sum(synth.COMP[bases.reshape(n, 150)[:, ::-1]].reshape(-1), offs) == base_sum, "4 M reads: reverse complement changes the rows"
+            assert run_sum(synth.COMP[bases.reshape(n, 150)[:, ::-1]].reshape(-1), offs) == base_sum, "full launch: reverse complement changes the rows"
             perm = np.random.default_rng(2).permutation(n)
-            assert run_sum(bases.reshape(n, 150)[perm].reshape(-1), offs, read_map=perm) == base_sum, "4 M reads: permutation changes the rows"
+            assert run_sum(bases.reshape(n, 150)[perm].reshape(-1), offs, read_map=perm) == base_sum, "full launch: permutation changes the rows"
             half = n // 2
             a = run_sum(bases[: half * 150], offs[: half + 1])
             b = run_sum(bases[half * 150:], offs[half:] - offs[half], read_add=half)
-            assert ((a[0] + b[0]) % (1 << 64), a[1] ^ b[1], a[2] + b[2]) == base_sum, "4 M reads: splitting the batch changes the rows"
+            assert ((a[0] + b[0]) % (1 << 64), a[1] ^ b[1], a[2] + b[2]) == base_sum, "full launch: splitting the batch changes the rows"
             stl.close()
     finally:
         dx.close()

@@ -218,6 +218,39 @@ def _bgzf_bytes(data, block=60000, level=1):
     return bytes(out)
 
 
+def test_steady_batches_of_the_pool_reader_are_one_chunk_each(capi, tmp_path):
+    """A batch of ordinary FASTQ is ONE parsed chunk, handed over as it is (the CLI's zero-copy path, kr_fastx_detach, needs a batch
+    that fits its job): a chunk of 2 * min_bases bytes holds about 0.94 * min_bases bases, which is a batch -- asking for all of
+    min_bases took a second chunk for every steady batch, appended by copy (37,736-read batches for a request of 20,000 reads)."""
+    rng = np.random.default_rng(3)
+    n, L = 200_000, 150
+    seqs = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(n, L))
+    with open(tmp_path / "r.fq", "wb") as f:
+        for i in range(n):
+            f.write(b"@read%07d\n" % i + seqs[i].tobytes() + b"\n+\n" + b"I" * L + b"\n")
+    lib = capi.load()
+    h = C.c_void_p()
+    capi.check(lib.kr_fastx_open(os.fsencode(str(tmp_path / "r.fq")), C.byref(h)))
+    sizes, total = [], 0
+    try:
+        while True:
+            b = capi.KrFastxBatch()
+            capi.check(lib.kr_fastx_next(h, 20_000 * L, C.byref(b)))
+            sizes.append(int(b.nreads))
+            total += int(b.nreads)
+            if not b.more:
+                break
+        lib.kr_fastx_parallel_chunks.restype = C.c_uint64
+        lib.kr_fastx_parallel_chunks.argtypes = [C.c_void_p]
+        chunks = int(lib.kr_fastx_parallel_chunks(h))
+    finally:
+        lib.kr_fastx_close(h)
+    assert total == n
+    steady = sizes[-6:-2]  # (the first chunks are short on purpose -- a ramp of growing chunks --, the last batches are what is left)
+    assert steady and max(sizes) <= 20_000 and min(steady) >= 17_500, sizes
+    assert chunks >= len(sizes) - 1 and chunks <= len(sizes) + 1, (chunks, len(sizes))
+
+
 def test_block_gzipped_input_is_inflated_in_parallel(capi, tmp_path):
     """BGZF files (bgzip, many sequencing pipelines): the members are inflated by several threads; the records are
     those of the plain file, standard tools still read the file, a damaged member is an error, not a silent stop."""
