@@ -198,6 +198,14 @@ KR_API void kr_stream_destroy(kr_stream*);
                            /* every rec_sel is 1, read_off / read_cnt are the reads' row ranges (a    */
                            /* tiled batch still comes back as record slots with flags: same fields,   */
                            /* same meaning, rec_sel 0 where a record is not a row)                    */
+#define KR_ROWS_INDEXED 32u /* with KR_ROWS_ONLY: DIST leaves the device as an INDEX -- the likelihood    */
+                           /* stage solves every distinct problem of a batch once (one in ~20 records), */
+                           /* so a row is (rec_key, rec_dix), 8 bytes across PCIe instead of 12, and    */
+                           /* the batch's distinct values come once: DIST of row i is                   */
+                           /* dist_list[rec_dix[i]] (bit for bit what rec_d would hold); rec_d of the    */
+                           /* host view is NULL then (a formatter may format each distinct value once). */
+                           /* A hint: honoured for batches that run as one lane and are not tiled --     */
+                           /* otherwise the view holds rec_d as without it (rec_dix == NULL says which). */
 
 /* Queue one batch: `bases` = concatenated ASCII sequences exactly as the FASTX
  * reader delivers them (QSeq::read_next_batch, src/rqseq.cpp:180-197),
@@ -241,6 +249,9 @@ typedef struct kr_result_view {
                               /* rec_hist[x * rec_hist_stride + i], x = 0..hdist_th       */
   uint64_t rec_hist_stride;
   uint64_t nrows;             /* number of rec_sel == 1                                  */
+  const uint32_t* rec_dix;    /* KR_ROWS_INDEXED (host view): [nrecs] index into dist_list, rec_d == NULL; else NULL */
+  const double* dist_list;    /* [ndist] distinct d_llh values of the batch (unused positions hold anything)         */
+  uint64_t ndist;
 } kr_result_view;
 
 /* Waits for the batch and copies results to pinned host memory owned by the stream (lane by lane: a lane's
@@ -251,6 +262,8 @@ KR_API int kr_batch_collect(kr_stream*, kr_result_view* out);
 /* As above but the arrays stay in HBM (device pointers); only counts are read back.  Device view: `nrecs` is
  * the extent of record slots handed out, unused slots (rec_key == 0) included; always go through read_off / read_cnt. */
 KR_API int kr_batch_collect_device(kr_stream*, kr_result_view* out);
+/* Bytes the last kr_batch_collect of a rows-only batch copied back over PCIe (measurement aid). */
+KR_API int kr_debug_last_d2h_bytes(kr_stream*, uint64_t* bytes);
 
 /* Debug taps (parity tests).  Hits: one entry per table entry with hd <= hdist_th. */
 typedef struct kr_hit {

@@ -19,7 +19,7 @@ KR_OK = 0
 KR_ERR_ARG, KR_ERR_IO, KR_ERR_FORMAT, KR_ERR_NO_DEVICE = -1, -2, -3, -4
 KR_ERR_NOMEM, KR_ERR_CAPACITY, KR_ERR_STATE, KR_ERR_UNSUPPORTED = -5, -6, -7, -8
 KR_VIEW_HOST, KR_VIEW_DEVICE = 0, 1
-KR_BASES_HOST, KR_BASES_DEVICE, KR_TAP_ACCS, KR_TAP_HITS, KR_BASES_PINNED, KR_ROWS_ONLY = 0, 1, 2, 4, 8, 16
+KR_BASES_HOST, KR_BASES_DEVICE, KR_TAP_ACCS, KR_TAP_HITS, KR_BASES_PINNED, KR_ROWS_ONLY, KR_ROWS_INDEXED = 0, 1, 2, 4, 8, 16, 32
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
@@ -52,7 +52,8 @@ class KrResultView(C.Structure):
     _fields_ = [("nreads", C.c_uint32), ("nrecs", C.c_uint32),
                 ("read_off", u32p), ("read_cnt", u32p), ("read_onmers", u32p), ("read_na", u8p),
                 ("rec_key", u32p), ("rec_sel", u8p), ("rec_d", f64p), ("rec_v", f64p),
-                ("rec_chisq", f64p), ("rec_hist", u32p), ("rec_hist_stride", C.c_uint64), ("nrows", C.c_uint64)]
+                ("rec_chisq", f64p), ("rec_hist", u32p), ("rec_hist_stride", C.c_uint64), ("nrows", C.c_uint64),
+                ("rec_dix", u32p), ("dist_list", f64p), ("ndist", C.c_uint64)]
 
 
 class KrHit(C.Structure):
@@ -90,7 +91,7 @@ EXPORTS = [
     "kr_debug_front_end", "kr_debug_stream_move", "kr_debug_stream_addrs", "kr_debug_item_placement", "kr_debug_brent", "kr_debug_colour_classes", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
     "kr_place_tree_create", "kr_place_tree_create_lineage", "kr_place_tree_nnodes", "kr_place_summary_add",
     "kr_place_summary_text", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_stream", "kr_place_frame", "kr_place_counters",
-    "kr_fastx_open", "kr_fastx_next", "kr_fastx_detach", "kr_fastx_release", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_fastx_pgz_stats", "kr_format_dist", "kr_debug_fixed5", "kr_free", "kr_host_alloc", "kr_host_free",
+    "kr_debug_last_d2h_bytes", "kr_fastx_open", "kr_fastx_next", "kr_fastx_detach", "kr_fastx_release", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_fastx_pgz_stats", "kr_format_dist", "kr_debug_fixed5", "kr_free", "kr_host_alloc", "kr_host_free",
     "kr_build_index", "kr_minimizers_cpu", "kr_minimizers_device", "kr_minimizers_free", "kr_last_error", "kr_version",
 ]
 
@@ -385,7 +386,13 @@ class Result:
         keep = key != 0  # record slots are handed out in per-wave chunks; key 0 marks an unused slot
         self.rec_key = key[keep]
         self.rec_sel = _np(rv.rec_sel, c, np.uint8)[keep]
-        self.rec_d = _np(rv.rec_d, c, np.float64)[keep]
+        if rv.rec_dix:  # KR_ROWS_INDEXED: DIST as an index into the batch's distinct values
+            self.rec_dix = _np(rv.rec_dix, c, np.uint32)[keep]
+            self.dist_list = _np(rv.dist_list, int(rv.ndist), np.float64)
+            self.rec_d = self.dist_list[self.rec_dix]
+        else:
+            self.rec_dix = None
+            self.rec_d = _np(rv.rec_d, c, np.float64)[keep]
         self.rec_v = _np(rv.rec_v, c, np.float64)[keep] if rv.rec_v else None       # NULL with KR_ROWS_ONLY
         self.rec_chisq = _np(rv.rec_chisq, c, np.float64)[keep] if rv.rec_chisq else None
         self.rec_hist = (_np(rv.rec_hist, c * np_planes, np.uint32).reshape(np_planes, -1).T[keep]
@@ -448,6 +455,12 @@ class Stream:
         check(self.lib.kr_batch_collect(self.h, C.byref(rv)))
         self._rv = rv
         return rv
+
+    def last_d2h_bytes(self):
+        b = C.c_uint64(0)
+        self.lib.kr_debug_last_d2h_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        check(self.lib.kr_debug_last_d2h_bytes(self.h, C.byref(b)))
+        return int(b.value)
 
     def collect_device(self):
         rv = KrResultView()

@@ -1678,7 +1678,7 @@ int kr_format_dist(const kr_host_index* h, const kr_result_view* rv, const char*
       for (uint32_t i = o; i < o + n; ++i) {
         if (!rv->rec_sel[i]) continue;
         const char* nm = kr_host_index_node_name(h, rv->rec_key[i] >> 1);
-        const size_t nl = fmt_fixed5(rv->rec_d[i], num);
+        const size_t nl = fmt_fixed5(rv->rec_dix ? rv->dist_list[rv->rec_dix[i]] : rv->rec_d[i], num); // (KR_ROWS_INDEXED: DIST through the batch's list)
         s.append(id, idl);
         s += '\t';
         s += nm;

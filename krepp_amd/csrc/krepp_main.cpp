@@ -241,12 +241,15 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
     }
     if (brc) error_exit(kr_last_error());
   }
-  // "Loading the index and initializing..." (src/krepp.cpp:756-757) ends when the workers have their streams: device buffers and
-  // page-locked staging are part of the initialisation, like the reference's index structures; the elapsed time reported at the
-  // end is that of the batch loop (estimate_distances(), src/krepp.cpp:759-762), taken when the last row has been written and
-  // before anything is torn down -- as the reference takes it before its destructors run
+  // "Loading the index and initializing..." (src/krepp.cpp:756-757) ends HERE, when the index is in device memory.  The elapsed
+  // time reported at the end is everything after it -- the workers' streams and page-locked buffers, then the batch loop
+  // (estimate_distances(), src/krepp.cpp:347-394,759-762: the reference's clock covers all it does after the index load, so this
+  // one does too since round 6; until then it began when the streams were ready) -- taken when the last row has been written and
+  // before anything is torn down, as the reference takes it before its destructors run.  The reader opens the query file and
+  // parses the first batches while the streams come up.
   auto t_init = std::chrono::steady_clock::now();
-  auto t0 = t_init; // (set again when the workers are ready)
+  const auto t0 = t_init;
+  auto t_loop = t_init; // when the workers were ready ([timing] only)
   if (seek) { // QuerySketch::header_dreport (src/krepp.cpp:305-309)
     fprintf(out, "# software: krepp\tversion: " KREPP_VERSION "\tinvocation :%s\nSEQ_ID\tDIST\n", invocation.c_str());
   } else if (!place) { // header (src/krepp.cpp:311-319)
@@ -314,7 +317,7 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
   std::atomic<int> worker_ids{0};
   int workers_ready = 0;
   std::vector<kr_stream*> streams_to_free;
-  kr_fastx* fx = nullptr; // (opened when the workers are ready; they hand batches back to it)
+  kr_fastx* fx = nullptr; // (opened before the workers start; they hand batches back to it)
   auto worker = [&](int g) {
     const int wid = worker_ids++;
     double t_ready = 0, t_first = -1, t_last = 0;
@@ -390,17 +393,33 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
         if (handed_over) cv_done.notify_all();
         auto t_w = now();
         if (at_off >= 0) {
+          // A batch's text is hundreds of megabytes (262,144 reads x 33 rows x 28 bytes), and one thread copies 2.5-5 GB/s into the
+          // page cache: with two workers the 38 GB of a 50 M-read run were written at 5 GB/s and the run was that (round 6,
+          // profiles/round6_cli_syn1000_50m.txt).  The text goes out in slices of at least 16 MB, side by side (KR_CLI_WRITE_THREADS,
+          // default 4 per worker).
           const int fd = fileno(out);
-          size_t done = 0;
-          while (done < n) {
-            const ssize_t w = pwrite(fd, p + done, n - done, at_off + (off_t)done);
-            if (w < 0) {
-              if (errno == EINTR) continue;
-              std::lock_guard<std::mutex> lk(mu);
-              worker_err = std::string("cannot write the output: ") + strerror(errno);
-              break;
+          auto write_slice = [&](size_t a, size_t b) {
+            size_t done = a;
+            while (done < b) {
+              const ssize_t w = pwrite(fd, p + done, b - done, at_off + (off_t)done);
+              if (w < 0) {
+                if (errno == EINTR) continue;
+                std::lock_guard<std::mutex> lk(mu);
+                worker_err = std::string("cannot write the output: ") + strerror(errno);
+                break;
+              }
+              done += (size_t)w;
             }
-            done += (size_t)w;
+          };
+          static const int wt_env = getenv("KR_CLI_WRITE_THREADS") ? std::max(1, atoi(getenv("KR_CLI_WRITE_THREADS"))) : 4;
+          const size_t nsl = std::max<size_t>(1, std::min<size_t>((size_t)wt_env, n >> 24));
+          if (nsl == 1) {
+            write_slice(0, n);
+          } else {
+            std::vector<std::thread> ws_;
+            for (size_t q = 1; q < nsl; ++q) ws_.emplace_back(write_slice, n * q / nsl, n * (q + 1) / nsl);
+            write_slice(0, n / nsl);
+            for (auto& t_ : ws_) t_.join();
           }
         } else if (n) {
           fwrite(p, 1, n, out);
@@ -517,6 +536,7 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
   // with 400,000-read batches through the C ABI a third host thread does pay: DESIGN.md 3.4)
   const int wpg = getenv("KR_CLI_WORKERS_PER_GPU") ? std::max(1, atoi(getenv("KR_CLI_WORKERS_PER_GPU"))) : 2;
   const int nworkers = ngpus * wpg;
+  if (kr_fastx_open(a.get("--query").c_str(), &fx)) error_exit(kr_last_error()); // (before the workers: they hand batches back to it)
   std::vector<std::thread> workers;
   for (int w = 0; w < nworkers; ++w) workers.emplace_back(worker, w % ngpus);
 
@@ -573,16 +593,19 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
     }
   });
 
-  {
-    std::unique_lock<std::mutex> lk(mu);
-    cv_done.wait(lk, [&] { return workers_ready == nworkers; });
-  }
   if (seek) fprintf(stderr, "Seeking query sequences in the sketch...\n");
   if (!place && !seek) fprintf(stderr, "Estimating distances between given sequences and references...\n");
-  t0 = std::chrono::steady_clock::now();
-  if (kr_fastx_open(a.get("--query").c_str(), &fx)) error_exit(kr_last_error());
+  std::thread ready_watch([&] { // ([timing]: when the last worker had its stream)
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return workers_ready == nworkers; });
+    t_loop = std::chrono::steady_clock::now();
+  });
   uint64_t nbatches = 0, nreads_total = 0;
   for (;;) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!worker_err.empty()) break; // (a worker without a stream, or one whose batch failed: reported below)
+    }
     kr_fastx_batch b;
     auto t_parse = now();
     if (kr_fastx_next(fx, batch_bases, &b)) error_exit(kr_last_error());
@@ -640,6 +663,7 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
   cv_done.notify_all();
   for (auto& w : workers) w.join();
   cv_done.notify_all();
+  ready_watch.join();
   writer.join();
   if (!worker_err.empty()) error_exit(worker_err);
   if (summarize && !place) // src/krepp.cpp:388-393 (ascending colour id instead of hash-map order)
@@ -671,8 +695,8 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
   fprintf(stderr, place ? "Done placing queries, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n" : seek ? "Done seeking query sequences, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n" : "Done estimating distances, elapsed: %g sec (%.0f reads/s on %d GPU(s))\n", sec,
           sec > 0 ? nreads_total / sec : 0.0, ngpus);
   if (timing)
-    fprintf(stderr, "[timing] parse %.3f s, job hand-over (incl. waiting for queue space) %.3f s, device %.3f s, format %.3f s, write %.3f s; initialisation after the index upload (streams, page-locked buffers) %.3f s\n",
-            ns_parse / 1e9, ns_job / 1e9, ns_dev / 1e9, ns_fmt / 1e9, ns_write / 1e9, std::chrono::duration<double>(t0 - t_init).count());
+    fprintf(stderr, "[timing] parse %.3f s, job hand-over (incl. waiting for queue space) %.3f s, device %.3f s, format %.3f s, write %.3f s; of the elapsed time, until the last worker had its stream and page-locked buffers: %.3f s (the reader parses meanwhile)\n",
+            ns_parse / 1e9, ns_job / 1e9, ns_dev / 1e9, ns_fmt / 1e9, ns_write / 1e9, std::chrono::duration<double>(t_loop - t_init).count());
   fprintf(stderr, "Total number of sequences queried: %llu\n", (unsigned long long)nreads_total);
   // Everything is written.  Unmapping 19 GB of index, 10 GB of host tables and the page-locked buffers one by one takes 0.8-1.2 s
   // that nobody is waiting for: the process ends here and the kernel reclaims the lot (KR_CLI_CLEAN_EXIT=1: free everything in

@@ -69,7 +69,9 @@ with open(fq, "wb") as f:
 print(f"set-up {time.time() - t0:.0f} s: index {nk * 8 / 1e9:.1f} GB in {idx}, {n} reads in {os.path.getsize(fq) / 1e9:.2f} GB of FASTQ", flush=True)
 
 exe = os.path.join(root, "krepp_amd", "lib", "krepp")
-out_file = os.path.join(work, "out.txt")
+# KR_TIME_CLI_OUT_DIR: where the report goes (default: the work directory, i.e. the box's disk; /dev/shm takes the disk out of the
+# measurement -- 38 GB of rows for 50 M reads are written at the disk's 5 GB/s otherwise, profiles/round6_cli_syn1000_50m*.txt)
+out_file = os.path.join(os.environ.get("KR_TIME_CLI_OUT_DIR", work), "krepp_cli_out.txt")
 configs = [
     ("dist", [], {}, out_file),
     ("dist", [], {"KR_CLI_HOST_TEXT": "1"}, out_file),  # the host formatter of rounds 1-4, same box

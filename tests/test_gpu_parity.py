@@ -530,6 +530,58 @@ def test_where_a_streams_buffers_lie_does_not_change_results(capi, toy, toy_geno
         st2.close()
 
 
+def test_indexed_rows_are_the_rows(capi, toy, toy_genomes, synth, monkeypatch):
+    """KR_ROWS_INDEXED: a rows-only batch whose DIST column crosses PCIe as an index into the batch's distinct likelihood
+    problems (8 bytes a row instead of 12, the distinct values once): the rows are bit for bit those of a plain rows-only
+    batch, the host formatter prints the same text from them, fewer bytes come back; a batch that runs as several lanes (or
+    filters) ignores the hint and returns rec_d as before (src/query.cpp:158-196 is what the rows are for)."""
+    hx, dx, ox = toy
+    bases, offs, names = synth.sample_reads(toy_genomes, 5003, seed=21)
+    n = len(offs) - 1
+    monkeypatch.setenv("KR_LANES", "1")
+    st = dx.stream(max_reads=n, max_bases=len(bases))
+    monkeypatch.delenv("KR_LANES")
+    st.submit(bases, offs, capi.KR_ROWS_ONLY)
+    plain = st.collect()
+    text = st.format_dist(hx, names)
+    b12 = st.last_d2h_bytes()
+    rows = lambda r: sorted(zip(r.rec_read.tolist(), r.rec_key.tolist(), r.rec_d.view(np.uint64).tolist()))
+    assert plain.rec_dix is None and plain.nrows == len(plain.rec_key) > n
+    for _ in range(2):  # (twice: the page-locked arrays of the first indexed batch are reused by the second)
+        st.submit(bases, offs, capi.KR_ROWS_ONLY | capi.KR_ROWS_INDEXED)
+        ix = st.collect()
+        # (the list is the extent of list positions the batch handed out, holes included: on a batch this small -- nearly every
+        #  problem distinct -- it is as long as the rows; tests/test_gpu_syn1000.py has the batch where it is a twentieth)
+        assert ix.rec_dix is not None and int(ix.rec_dix.max()) < len(ix.dist_list)
+        assert rows(ix) == rows(plain) and ix.read_na.tolist() == plain.read_na.tolist()
+        assert st.format_dist(hx, names) == text
+        assert st.last_d2h_bytes() == 9 * n + 8 * len(ix.rec_key) + 8 * len(ix.dist_list) and b12 == 9 * n + 12 * len(ix.rec_key)
+    # a plain batch after an indexed one on the same stream
+    st.submit(bases, offs, capi.KR_ROWS_ONLY)
+    again = st.collect()
+    assert again.rec_dix is None and rows(again) == rows(plain)
+    st.close()
+    # several lanes: the hint is ignored
+    monkeypatch.setenv("KR_LANE_MIN_READS", "500")
+    monkeypatch.setenv("KR_LANES", "3")
+    st3 = dx.stream(max_reads=n, max_bases=len(bases))
+    st3.submit(bases, offs, capi.KR_ROWS_ONLY | capi.KR_ROWS_INDEXED)
+    r3 = st3.collect()
+    assert st3.timing().lanes == 3 and r3.rec_dix is None and rows(r3) == rows(plain)
+    st3.close()
+    # --filter: the hint is ignored (the select kernel writes the objective values the list would alias)
+    pf = capi.default_params()
+    pf.no_filter = 0
+    monkeypatch.setenv("KR_LANES", "1")
+    stf = dx.stream(pf, max_reads=n, max_bases=len(bases))
+    stf.submit(bases, offs, capi.KR_ROWS_ONLY)
+    want = stf.collect()
+    stf.submit(bases, offs, capi.KR_ROWS_ONLY | capi.KR_ROWS_INDEXED)
+    got = stf.collect()
+    assert got.rec_dix is None and rows(got) == rows(want)
+    stf.close()
+
+
 def test_lanes_do_not_change_results(capi, toy, toy_genomes, synth, monkeypatch):
     """A batch cut into several lanes (own HIP stream, own H2D/D2H copies, slices of the result arrays) returns what one
     lane returns: records, histograms, rows, report text; host view, device view, KR_ROWS_ONLY and KR_BASES_PINNED."""

@@ -157,6 +157,18 @@ def test_syn1000_10gb_index_vs_oracle_and_full_batch_properties(capi, po, synth,
 
             base_sum = run_sum(bases, offs)
             assert base_sum[2] > 20 * n
+            plain_bytes = stl.last_d2h_bytes()
+            if slot_log2w == "6":  # KR_ROWS_INDEXED at the size it is for: the same rows, DIST as an index into a list a twentieth their number
+                monkeypatch.setenv("KR_LANES", "1")
+                sti = dx.stream(max_reads=n, max_bases=len(bases), max_records=n * 64)
+                monkeypatch.delenv("KR_LANES")
+                sti.submit(bases, offs, capi.KR_ROWS_ONLY | capi.KR_ROWS_INDEXED)
+                ri = sti.collect()
+                assert ri.rec_dix is not None and 0 < len(ri.dist_list) < len(ri.rec_key) // 8
+                assert rows_checksum(ri.rec_read.astype(np.int64), ri.rec_key >> 1, ri.rec_d.view(np.uint64)) == base_sum, "indexed rows differ"
+                assert sti.last_d2h_bytes() < 0.72 * plain_bytes
+                del ri
+                sti.close()
             assert run_sum(synth.COMP[bases.reshape(n, 150)[:, ::-1]].reshape(-1), offs) == base_sum, "full launch: reverse complement changes the rows"
             perm = np.random.default_rng(2).permutation(n)
             assert run_sum(bases.reshape(n, 150)[perm].reshape(-1), offs, read_map=perm) == base_sum, "full launch: permutation changes the rows"

@@ -30,7 +30,7 @@ def test_struct_sizes_match_header(capi):
     assert C.sizeof(capi.KrLibView) == 4 * 8 + 8 + 6 * 4
     assert C.sizeof(capi.KrParams) == 32
     assert C.sizeof(capi.KrHit) == 32
-    assert C.sizeof(capi.KrResultView) == 8 + 10 * 8 + 8 + 8
+    assert C.sizeof(capi.KrResultView) == 8 + 10 * 8 + 8 + 8 + 3 * 8
     assert C.sizeof(capi.KrTiming) == 32
 
 
