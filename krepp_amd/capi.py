@@ -731,9 +731,11 @@ class Placer:
         self.lib.kr_free(txt)
         return s
 
-    def place(self, bases, offsets, names, host=False, c_names=None, want_placements=True):
+    def place(self, bases, offsets, names, host=False, c_names=None, want_placements=True, keep_text=True):
         """One batch.  host=False: kr_place_stream (tree aggregation and likelihoods on the device);
-        host=True: kr_batch_collect + kr_place_batch (aggregation on the host).  Same output."""
+        host=True: kr_batch_collect + kr_place_batch (aggregation on the host).  Same output.
+        keep_text=False (timing): the library's text and placements are not copied into Python objects -- copying and decoding 70 MB
+        of jplace text takes Python longer than the library takes to make it; returns (bytes of text, number of placements)."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self.st.submit(bases, offsets, KR_TAP_ACCS)
@@ -749,6 +751,12 @@ class Placer:
             check(self.lib.kr_place_stream(self.hx.h, self.dx.h, self.pt, self.st.h, len(offsets) - 1, offsets.ctypes.data, arr,
                                            C.byref(self.popts), int(self.tabular), C.byref(self.prev), C.byref(txt), C.byref(ln),
                                            C.byref(pls) if want_placements else None, C.byref(npl) if want_placements else None))
+        if not keep_text:
+            if int(self.tabular) == 2:
+                check(self.lib.kr_place_summary_add(self.pt, pls, npl.value, self.wcount.ctypes.data, C.byref(self.twcount)))
+            self.lib.kr_free(txt)
+            self.lib.kr_free(pls)
+            return int(ln.value), int(npl.value)
         text = C.string_at(txt, ln.value).decode()
         pl = (np.frombuffer(C.string_at(pls, npl.value * PLACEMENT_DT.itemsize), dtype=PLACEMENT_DT).copy()
               if npl.value else np.zeros(0, PLACEMENT_DT))

@@ -87,6 +87,7 @@ KR_HD inline bool fixed5_exact(double v, uint32_t* n_out)
   uint32_t n = (uint32_t)fl;
   const double t = fr - 0.5; // exact: fr in [0, 1) is a multiple of ulp(sc) <= 2^-26, and so is 1/2
   if (t > 0.0 || (t == 0.0 && (err > 0.0 || (err == 0.0 && (n & 1u))))) ++n;
+  if (n >= 100000000u) return false; // (v in [999.999995, 1000) rounds to "1000.00000": ten bytes, one more than the callers lay out)
   *n_out = n;
   return true;
 }
@@ -195,6 +196,16 @@ int place_device_launch(kr_stream* s, const PlaceTreeArrays& T, uint32_t r0, uin
 int place_device_finish(kr_stream* s, const PlaceTreeArrays& T, uint32_t r0, uint32_t n, uint32_t tau, bool no_filter, double chisq,
                         uint64_t kept_base, PlaceDeviceResult* out);
 uint32_t place_stream_nreads(const kr_stream* s);
+// Large host buffers the library hands to its caller (report text: tens of megabytes a batch) and its large temporaries: a block
+// given back (kr_free / big_free) is kept -- up to a bound -- and handed out again, pages already touched.  glibc maps a block of
+// more than 32 MB afresh on every malloc and unmaps it on free: 280 MB of page faults per kr_place_stream call, taken under the
+// process's mmap lock by sixteen threads at once, were most of that call's host time (round 6).
+void* big_alloc(size_t n);
+void big_free(void* p);
+// Error path of kr_place_stream: whatever place_device_launch queued for a later range (kernels, the copy into the page-locked
+// counters) runs to its end before the stream is used again.  A PlaceDeviceResult is invalid after the next place_device_finish
+// on its stream (the page-locked arrays it points to may have been renewed).
+void place_device_abort(kr_stream* s);
 
 } // namespace kr
 

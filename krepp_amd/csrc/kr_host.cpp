@@ -1777,9 +1777,60 @@ uint32_t kr_debug_fixed5(double v, char* out)
   return l;
 }
 
-void kr_free(void* p) { free(p); }
+void kr_free(void* p) { kr::big_free(p); }
 
 const char* kr_last_error(void) { return kr::g_err.c_str(); }
 const char* kr_version(void) { return "krepp-amd 0.1.0 (mirrors krepp v0.8.3 dist)"; }
 
 } // extern "C"
+
+// ---- kr::big_alloc / big_free (kr_common.h)
+namespace {
+std::mutex g_big_mu;
+std::unordered_map<void*, size_t> g_big_live;            // blocks handed out by big_alloc: their capacities
+std::vector<std::pair<void*, size_t>> g_big_cache;        // blocks given back, kept for the next big_alloc
+size_t g_big_cached = 0;
+constexpr size_t kBigMin = 1u << 20, kBigCacheBytes = 3ull << 30, kBigCacheBlocks = 64;
+} // namespace
+void* kr::big_alloc(size_t n)
+{
+  if (n < kBigMin) return malloc(n);
+  {
+    std::lock_guard<std::mutex> lk(g_big_mu);
+    size_t best = g_big_cache.size();
+    for (size_t i = 0; i < g_big_cache.size(); ++i)
+      if (g_big_cache[i].second >= n && g_big_cache[i].second <= 2 * n + (8u << 20) && (best == g_big_cache.size() || g_big_cache[i].second < g_big_cache[best].second)) best = i;
+    if (best != g_big_cache.size()) {
+      const auto blk = g_big_cache[best];
+      g_big_cache[best] = g_big_cache.back();
+      g_big_cache.pop_back();
+      g_big_cached -= blk.second;
+      g_big_live[blk.first] = blk.second;
+      return blk.first;
+    }
+  }
+  const size_t cap = n + n / 8 + 4096;
+  void* p = malloc(cap);
+  if (!p) return nullptr;
+  std::lock_guard<std::mutex> lk(g_big_mu);
+  g_big_live[p] = cap;
+  return p;
+}
+void kr::big_free(void* p)
+{
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_big_mu);
+    auto it = g_big_live.find(p);
+    if (it != g_big_live.end()) {
+      const size_t cap = it->second;
+      g_big_live.erase(it);
+      if (g_big_cached + cap <= kBigCacheBytes && g_big_cache.size() < kBigCacheBlocks) {
+        g_big_cache.emplace_back(p, cap);
+        g_big_cached += cap;
+        return;
+      }
+    }
+  }
+  free(p);
+}

@@ -396,49 +396,95 @@ int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
   const int nt = std::max(1, std::min(std::min(kr::parallel_width(), 32), (int)(nreads / 4096)));
   auto en = [&](uint32_t q) { return q - 1; };
   auto mid = [&](uint32_t q) { return std::isnan(pt->t.nodes[q].blen) ? 0.0 : pt->t.nodes[q].blen / 2.0; };
-  auto num = [](std::string& o, double v) {
-    char b[64];
+  // Round 6: the text goes into a raw, growing byte buffer per thread -- room is checked once per number or name, bytes are
+  // stored through a pointer -- instead of a std::string appended to character by character (25 appends per placement, each with
+  // its capacity test: 13-27 ms per 200,000 reads of jplace on 16 threads, the longest phase of a kr_place_stream call on the
+  // 1000-genome tree; profiles/round6_place_big_tree.txt)
+  struct OutBuf {
+    char* b = nullptr;
+    size_t n = 0, cap = 0;
+    bool oom = false;
+    OutBuf() = default;
+    OutBuf(const OutBuf&) = delete;
+    OutBuf& operator=(const OutBuf&) = delete;
+    ~OutBuf() { kr::big_free(b); }
+    void need(size_t k)
+    {
+      if (n + k <= cap) return;
+      const size_t nc = std::max(cap + cap / 2, n + k + 65536);
+      char* nb = (char*)kr::big_alloc(nc);
+      if (!nb) { // (keeps writing into what it has, from the start: the caller reports the failure)
+        oom = true, n = 0;
+        if (cap < k + 65536) {
+          kr::big_free(b);
+          b = (char*)malloc(k + 65536), cap = b ? k + 65536 : 0;
+        }
+        return;
+      }
+      if (n) memcpy(nb, b, n);
+      kr::big_free(b);
+      b = nb, cap = nc;
+    }
+    void put(char c) { b[n++] = c; }
+    void lit(const char* s_, size_t l) { memcpy(b + n, s_, l), n += l; }
+    bool empty() const { return n == 0; }
+    size_t size() const { return n; }
+    const char* data() const { return b; }
+  };
+  auto num = [](OutBuf& o, double v) { // "%.5f" (the reference's stream settings: std::fixed, 5 decimals)
+    o.need(80);
     if (std::isnan(v)) {
-      o += std::signbit(v) ? "-nan" : "nan";
+      if (std::signbit(v)) o.put('-');
+      o.lit("nan", 3);
       return;
     }
-    o.append(b, kr::fmt_fixed5(v, b));
+    uint32_t nn;
+    const double av = std::fabs(v);
+    if (kr::fixed5_exact(av, &nn)) { // printf's digits, exactly (kr_common.h)
+      if (std::signbit(v)) o.put('-');
+      o.n += kr::fixed5_digits(nn, o.b + o.n);
+    } else {
+      o.n += kr::fmt_fixed5(v, o.b + o.n);
+    }
   };
-  auto unum = [](std::string& o, uint32_t v) { // decimal, no allocation
-    char b[12];
-    int n = 0;
-    do b[n++] = (char)('0' + v % 10u), v /= 10u;
+  auto unum = [](OutBuf& o, uint32_t v) { // decimal
+    o.need(12);
+    char t_[12];
+    int k_ = 0;
+    do t_[k_++] = (char)('0' + v % 10u), v /= 10u;
     while (v);
-    while (n) o += b[--n];
+    while (k_) o.put(t_[--k_]);
   };
   const bool want_pl = placements && nplacements;
-  auto jfields = [&](std::string& o, uint32_t q, const CandLite& a) {
-    o += '[';
+  auto jfields = [&](OutBuf& o, uint32_t q, const CandLite& a) {
+    o.need(16);
+    o.put('[');
     unum(o, en(q));
-    o += ", ", num(o, a.jc() - mid(q));
-    o += ", ", num(o, mid(q));
-    o += ", ", num(o, -a.v);
-    o += ", ", num(o, a.lwr);
-    o += ", ", num(o, a.d);
-    o += ']';
+    o.need(4), o.lit(", ", 2), num(o, a.jc() - mid(q));
+    o.need(4), o.lit(", ", 2), num(o, mid(q));
+    o.need(4), o.lit(", ", 2), num(o, -a.v);
+    o.need(4), o.lit(", ", 2), num(o, a.lwr);
+    o.need(4), o.lit(", ", 2), num(o, a.d);
+    o.need(4), o.put(']');
   };
-  auto tfields = [&](std::string& o, uint32_t q, const CandLite& a) {
+  auto tfields = [&](OutBuf& o, uint32_t q, const CandLite& a) {
     const std::string& nm = pt->t.nodes[q].label;
+    o.need(nm.size() + 8);
     if (nm.empty())
-      o += "NA";
+      o.lit("NA", 2);
     else
-      o += nm;
-    o += '\t';
+      o.lit(nm.data(), nm.size());
+    o.put('\t');
     unum(o, en(q));
-    o += '\t', num(o, a.lwr);
-    o += '\t', num(o, a.d);
+    o.need(4), o.put('\t'), num(o, a.lwr);
+    o.need(4), o.put('\t'), num(o, a.d);
   };
   const bool jp = tabular == 0, tb = tabular == 1; // 2: --summarize, no text (the caller sums the placements)
-  std::vector<std::string> part((size_t)nt);
+  std::vector<OutBuf> part((size_t)nt);
   std::vector<std::vector<kr_placement>> ppls((size_t)nt);
   kr::parallel_for(nt, [&](int t) {
     const uint32_t ra = r_begin + (uint32_t)((uint64_t)nreads * t / nt), rb = r_begin + (uint32_t)((uint64_t)nreads * (t + 1) / nt);
-    std::string& out = part[(size_t)t];
+    OutBuf& out = part[(size_t)t];
     std::vector<kr_placement>& pls = ppls[(size_t)t];
     bool prev = false; // within the piece; pieces are joined with the separator below
     auto record = [&](uint32_t r, uint32_t q, const CandLite& a) {
@@ -449,27 +495,34 @@ int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
     };
     std::vector<size_t> nd_v;
     std::vector<CandLite> cands; // the read's candidates
-    out.reserve((size_t)(rb - ra) * (jp ? 160 : tb ? 72 : 0) + 64);
+    out.need((size_t)(rb - ra) * (jp ? 224 : tb ? 96 : 0) + 256);
     if (want_pl) pls.reserve((size_t)(rb - ra) * 2);
     for (uint32_t r = ra; r < rb; ++r) {
       if (!src.reported(r)) continue;
       struct { bool single; size_t c0, c1; } pl{src.single(r), 0, 0};
       pl.c1 = src.fetch(r, cands);
       const char* id = names ? names[r] : "";
+      const size_t idl = strlen(id);
+      auto lit = [&](const char* s_) { const size_t l_ = strlen(s_); out.need(l_ + 8), out.lit(s_, l_); };
+      auto tline = [&](const CandLite& c_) { // SEQ_ID \t fields \n
+        out.need(idl + 8), out.lit(id, idl), out.put('\t');
+        tfields(out, c_.se, c_);
+        out.need(4), out.put('\n');
+      };
       if (jp) {
-        if (prev) out += ",\n";
-        out += "\t\t\t{\"n\" : [\"";
-        out += id;
-        out += "\"], \"p\" : [";
+        if (prev) lit(",\n");
+        lit("\t\t\t{\"n\" : [\"");
+        out.need(idl + 8), out.lit(id, idl);
+        lit("\"], \"p\" : [");
         prev = true;
       }
       if (pl.single) {
         CandLite& c = cands[pl.c0];
         record(r, c.se, c);
         if (tb)
-          out += id, out += '\t', tfields(out, c.se, c), out += '\n';
+          tline(c);
         else if (jp)
-          jfields(out, c.se, c), out += "]}";
+          jfields(out, c.se, c), lit("]}");
         continue;
       }
       nd_v.clear();
@@ -485,13 +538,13 @@ int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
           CandLite& c = cands[nd_v[j2]];
           c.lwr = c.lwr / total;
           record(r, c.se, c);
-          if (j2 > 0 && jp) out += ",";
+          if (j2 > 0 && jp) lit(",");
           if (tb)
-            out += id, out += '\t', tfields(out, c.se, c), out += '\n';
+            tline(c);
           else if (jp)
-            out += "\n\t\t\t\t", jfields(out, c.se, c);
+            lit("\n\t\t\t\t"), jfields(out, c.se, c);
         }
-        if (jp) out += "]\n\t\t\t}";
+        if (jp) lit("]\n\t\t\t}");
       } else {
         if (nd_v.size() > 1)
           std::stable_sort(nd_v.begin(), nd_v.end(), [&](size_t l, size_t rr) {
@@ -499,20 +552,22 @@ int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
             return cl_ == cr ? cands[l].d > cands[rr].d : cl_ < cr;
           });
         if (nd_v.empty()) {
-          if (jp) out += "]}";
+          if (jp) lit("]}");
           continue;
         }
         CandLite& c = cands[nd_v.back()];
         c.lwr = c.lwr / total;
         record(r, c.se, c);
         if (tb)
-          out += id, out += '\t', tfields(out, c.se, c), out += '\n';
+          tline(c);
         else if (jp)
-          jfields(out, c.se, c), out += "]}";
+          jfields(out, c.se, c), lit("]}");
       }
     }
   });
   lap("D: filter + text");
+  for (auto& pb_ : part)
+    if (pb_.oom) return kr::fail(KR_ERR_NOMEM, "kr_place_batch: out of memory");
   // pieces joined in order, straight into the buffer the caller receives
   bool prev = *has_previous != 0;
   std::vector<size_t> at((size_t)nt + 1, 0), sep((size_t)nt, 0), pat((size_t)nt + 1, 0);
@@ -525,13 +580,13 @@ int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
     pat[(size_t)t + 1] = pat[(size_t)t] + ppls[(size_t)t].size();
   }
   const size_t total_len = at[(size_t)nt], total_pl = pat[(size_t)nt];
-  char* buf = (char*)malloc(total_len + 1);
+  char* buf = (char*)kr::big_alloc(total_len + 1);
   if (!buf) return kr::fail(KR_ERR_NOMEM, "kr_place_batch: out of memory");
   kr_placement* pbuf = nullptr;
   if (placements && nplacements) {
-    pbuf = (kr_placement*)malloc(std::max<size_t>(1, total_pl) * sizeof(kr_placement));
+    pbuf = (kr_placement*)kr::big_alloc(std::max<size_t>(1, total_pl) * sizeof(kr_placement));
     if (!pbuf) {
-      free(buf);
+      kr::big_free(buf);
       return kr::fail(KR_ERR_NOMEM, "kr_place_batch: out of memory");
     }
   }
@@ -861,7 +916,7 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
   struct Piece { char* text = nullptr; uint64_t len = 0; kr_placement* pl = nullptr; uint64_t npl = 0; };
   std::vector<Piece> pieces(nranges);
   auto drop = [&]() {
-    for (auto& pc : pieces) free(pc.text), free(pc.pl);
+    for (auto& pc : pieces) kr::big_free(pc.text), kr::big_free(pc.pl);
   };
   uint64_t kept_base = 0, heavy = 0;
   int prev = *has_previous;
@@ -901,7 +956,8 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
   }
   if (rc) {
     drop();
-    (void)kr_batch_wait(s); // (whatever was queued runs to its end before the stream is used again)
+    kr::place_device_abort(s); // (the next range's kernels and its copy into the page-locked counters are in flight -- kr_batch_wait
+                               //  returns at once here, the batch was waited for long ago: round-5 advice)
     return rc;
   }
   if (overflow) { // out of candidate slots beyond what a rerun can name: the host back end takes the whole batch
@@ -917,18 +973,22 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
   } else {
     uint64_t tl = 0, tp = 0;
     for (auto& pc : pieces) tl += pc.len, tp += pc.npl;
-    char* buf = (char*)malloc(tl + 1);
-    kr_placement* pb = (placements && nplacements) ? (kr_placement*)malloc(std::max<uint64_t>(1, tp) * sizeof(kr_placement)) : nullptr;
+    char* buf = (char*)kr::big_alloc(tl + 1);
+    kr_placement* pb = (placements && nplacements) ? (kr_placement*)kr::big_alloc(std::max<uint64_t>(1, tp) * sizeof(kr_placement)) : nullptr;
     if (!buf || ((placements && nplacements) && !pb)) {
-      free(buf), free(pb);
+      kr::big_free(buf), kr::big_free(pb);
       drop();
       return kr::fail(KR_ERR_NOMEM, "kr_place_stream: out of memory");
     }
     std::vector<uint64_t> at(nranges + 1, 0), pat(nranges + 1, 0);
     for (uint32_t k = 0; k < nranges; ++k) at[k + 1] = at[k] + pieces[k].len, pat[k + 1] = pat[k] + pieces[k].npl;
-    kr::parallel_for((int)nranges, [&](int k) {
-      if (pieces[(size_t)k].len) memcpy(buf + at[(size_t)k], pieces[(size_t)k].text, pieces[(size_t)k].len);
-      if (pb && pieces[(size_t)k].npl) memcpy(pb + pat[(size_t)k], pieces[(size_t)k].pl, pieces[(size_t)k].npl * sizeof(kr_placement));
+    // (in slices, side by side: two threads copying 35 MB each into fresh pages took 13 ms of a 58 ms jplace call)
+    const int sl = std::max(1, std::min(kr::parallel_width(), 16) / (int)nranges);
+    kr::parallel_for((int)nranges * sl, [&](int q) {
+      const size_t k = (size_t)(q / sl), part_ = (size_t)(q % sl);
+      const uint64_t l0 = pieces[k].len * part_ / sl, l1 = pieces[k].len * (part_ + 1) / sl;
+      if (l1 > l0) memcpy(buf + at[k] + l0, pieces[k].text + l0, l1 - l0);
+      if (pb && part_ == 0 && pieces[k].npl) memcpy(pb + pat[k], pieces[k].pl, pieces[k].npl * sizeof(kr_placement));
     });
     buf[tl] = 0;
     drop();
@@ -953,10 +1013,16 @@ int kr_place_summary_add(const kr_place_tree* pt, const kr_placement* pls, uint6
 { // place --summarize: a read with m placements counts 1/m at each (src/query.cpp:232-233,297-298,322-323);
   // summed per 512 reads first, as the reference's batches are (src/krepp.cpp:466-471)
   if (!pt || (!pls && n) || !wcount || !twcount) return kr::fail(KR_ERR_ARG, "kr_place_summary_add: null argument");
-  std::map<uint32_t, double> part;
+  // the group's sums in a dense array + the list of nodes it touched, flushed in ascending node order: the additions a std::map
+  // keyed by node made (until round 6: 60 ms per 880,000 placements, most of a `--summarize` call), in the same order
+  const uint32_t nn_ = pt->t.nnodes();
+  std::vector<double> part((size_t)nn_ + 2, 0.0);
+  std::vector<uint8_t> seen((size_t)nn_ + 2, 0);
+  std::vector<uint32_t> touched;
   auto flush = [&]() {
-    for (auto& kv : part) *twcount += kv.second, wcount[kv.first] += kv.second;
-    part.clear();
+    std::sort(touched.begin(), touched.end());
+    for (uint32_t k_ : touched) *twcount += part[k_], wcount[k_] += part[k_], part[k_] = 0.0, seen[k_] = 0;
+    touched.clear();
   };
   for (uint64_t i = 0; i < n;) {
     uint64_t j = i;
@@ -964,7 +1030,9 @@ int kr_place_summary_add(const kr_place_tree* pt, const kr_placement* pls, uint6
     if (i && (pls[i].read >> 9) != (pls[i - 1].read >> 9)) flush();
     for (uint64_t q = i; q < j; ++q) {
       if (pls[q].edge + 1 > pt->t.nnodes()) return kr::fail(KR_ERR_ARG, "kr_place_summary_add: edge out of range");
-      part[pls[q].edge + 1] += 1.0 / (double)(j - i);
+      const uint32_t k_ = pls[q].edge + 1;
+      if (!seen[k_]) seen[k_] = 1, touched.push_back(k_);
+      part[k_] += 1.0 / (double)(j - i);
     }
     i = j;
   }

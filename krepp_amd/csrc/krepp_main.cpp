@@ -472,6 +472,7 @@ static int run_query(const Args& a, const std::string& invocation, int mode)
         if (!rc && seek) rc = kr_format_seek(hx, dix[g], &rv, p.hdist_th, nm + lo, &txt, &len);
         if (!rc && on_device) {
           emit(dtext, dlen, lo == 0 && hi == job_n);
+          if (piece != SIZE_MAX && ++streak >= 16) piece = piece > SIZE_MAX / 2 ? SIZE_MAX : piece * 2, streak = 0; // (as below: grow back after a run of successes)
           return 0;
         }
         if (!rc && !place && !seek && !summarize) rc = kr_format_dist(hx, &rv, nm + lo, &txt, &len);

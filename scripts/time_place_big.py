@@ -20,27 +20,39 @@ o = np.arange(n + 1, dtype=np.uint64) * np.uint64(150)
 names = [f"q{i}" for i in range(n)]
 arr = (C.c_char_p * n)(*[x.encode() for x in names])
 hx = capi.HostIndex(idx)
+only = os.environ.get("KR_TIME_PLACE_ONLY")  # e.g. "jplace": that mode's single calls only (with KR_PLACE_TIMING=1: the phases of a call)
 for tab, label in ((1, "--tabular"), (2, "--summarize"), (0, "jplace")):
+    if only and label.lstrip("-") != only:
+        continue
     pl = capi.Placer(hx, None, 0, tabular=tab, max_reads=n, max_bases=len(b))
     pl.place(b, o, names, c_names=arr, want_placements=(tab == 2))  # warm-up: workspaces
     d0, h0 = capi.place_counters()
     hv0 = capi.place_heavy_reads()
-    best = 1e9
+    best = best_py = 1e9
     for _ in range(3):
         pl.prev = C.c_int(0)
         t = time.time()
         text, p = pl.place(b, o, names, c_names=arr, want_placements=(tab == 2))
+        best_py = min(best_py, time.time() - t)
+    # Round 6: the LIBRARY's time -- the call above also copies the text into a Python string and decodes it (70 MB of jplace
+    # text: longer than the library takes to make it) and, for --summarize, copies the placements into a numpy array; until round
+    # 6 that was in the figure quoted as `a call`
+    for _ in range(5):
+        pl.prev = C.c_int(0)
+        t = time.time()
+        tl, npl_ = pl.place(b, o, names, c_names=arr, want_placements=(tab == 2), keep_text=False)
         best = min(best, time.time() - t)
     d1, h1 = capi.place_counters()
-    print(f"{label}: {n} reads, submit to text {best * 1e3:.1f} ms = {n / best / 1e6:.2f} M reads/s; device batches {d1 - d0}, host fallbacks {h1 - h0}, "
-          f"heavy reads (upper bound, 3 runs) {capi.place_heavy_reads() - hv0}; text {len(text) / 1e6:.1f} MB")
+    print(f"{label}: {n} reads, submit to text {best * 1e3:.1f} ms = {n / best / 1e6:.2f} M reads/s (library: kr_batch_submit + kr_place_stream; "
+          f"{best_py * 1e3:.1f} ms = {n / best_py / 1e6:.2f} M reads/s with the text copied into a Python string as rounds 3-5 timed it); "
+          f"device batches {d1 - d0}, host fallbacks {h1 - h0}, heavy reads (upper bound) {capi.place_heavy_reads() - hv0}; text {len(text) / 1e6:.1f} MB")
     pl.close()
 
 # NT host threads with a stream each (as the CLI's workers run; ctypes releases the GIL): one thread's last phase on the host while
 # another's batch is on the device -- the throughput of kr_place_stream as a pipeline
 import threading
-for NT in (2, 3, 4):
-  for tab, label in ((1, "--tabular"), (2, "--summarize")):
+for NT in (() if only else (2, 3, 4)):
+  for tab, label in ((0, "jplace"), (1, "--tabular"), (2, "--summarize")):
     pl = capi.Placer(hx, None, 0, tabular=tab, max_reads=n, max_bases=len(b))
     sts = [pl.st] + [pl.dx.stream(params=pl.st.params, max_reads=n, max_bases=len(b), max_records=n * 128) for _ in range(NT - 1)]
     ob = (len(b) + 7) & ~7

@@ -164,9 +164,10 @@ def test_syn1000_10gb_index_vs_oracle_and_full_batch_properties(capi, po, synth,
                 monkeypatch.delenv("KR_LANES")
                 sti.submit(bases, offs, capi.KR_ROWS_ONLY | capi.KR_ROWS_INDEXED)
                 ri = sti.collect()
-                assert ri.rec_dix is not None and 0 < len(ri.dist_list) < len(ri.rec_key) // 8
+                assert ri.rec_dix is not None and 0 < len(ri.dist_list) < len(ri.rec_key) // 4
                 assert rows_checksum(ri.rec_read.astype(np.int64), ri.rec_key >> 1, ri.rec_d.view(np.uint64)) == base_sum, "indexed rows differ"
-                assert sti.last_d2h_bytes() < 0.72 * plain_bytes
+                print(f"indexed rows: {sti.last_d2h_bytes() / 1e9:.2f} GB back against {plain_bytes / 1e9:.2f} GB, {len(ri.dist_list)} list entries for {ri.nrows} rows")
+                assert sti.last_d2h_bytes() < 0.8 * plain_bytes
                 del ri
                 sti.close()
             assert run_sum(synth.COMP[bases.reshape(n, 150)[:, ::-1]].reshape(-1), offs) == base_sum, "full launch: reverse complement changes the rows"

@@ -492,8 +492,9 @@ def test_device_formatter_rounding_is_printfs(capi):
         chk(v), chk(float(np.nextafter(v, 1.0))), chk(float(np.nextafter(v, 0.0)))
     for v in (0.0, 1e-10, 0.5, 0.499995, 9.999995, 99.999995, 999.99999):
         chk(v)
-    for v in (-1e-9, 1000.0, float("nan"), float("inf")):
-        assert lib.kr_debug_fixed5(v, buf) == 0
+    for v in (-1e-9, 1000.0, 999.999995, 999.9999999, float(np.nextafter(1000.0, 0.0)), float("nan"), float("inf")):
+        assert lib.kr_debug_fixed5(v, buf) == 0  # (values that round to "1000.00000" are out of range too: ten bytes)
+    chk(999.99999), chk(999.999994)
     # the text entry points check their arguments before anything touches a device
     txt, ln = C.c_void_p(), C.c_uint64()
     assert lib.kr_stream_text_enable(None, None, 1, 1) == capi.KR_ERR_ARG
