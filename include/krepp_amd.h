@@ -264,6 +264,8 @@ KR_API int kr_batch_collect(kr_stream*, kr_result_view* out);
 KR_API int kr_batch_collect_device(kr_stream*, kr_result_view* out);
 /* Bytes the last kr_batch_collect of a rows-only batch copied back over PCIe (measurement aid). */
 KR_API int kr_debug_last_d2h_bytes(kr_stream*, uint64_t* bytes);
+/* Tests: one number as `krepp place` rows print it (std::fixed, 5 decimals; `out` holds 80 bytes); returns its length. */
+KR_API int kr_debug_place_fixed5(double v, char* out);
 
 /* Debug taps (parity tests).  Hits: one entry per table entry with hd <= hdist_th. */
 typedef struct kr_hit {

@@ -385,17 +385,6 @@ struct CandLite { // what the last phase needs of a candidate
   double jc() const { return -0.75 * log(1 - 4.0 / 3.0 * d); }
 };
 
-// Last phase of report_placement (src/query.cpp:283-331) for a whole batch: chi-square filter, LWR, selection, text.
-// `cand(i)` gives candidate i; a read's candidates [c0, c1) are in ascending node number.
-// `src`: reported(r), single(r), fetch(r, buf) -> fills buf with the read's candidates in ascending node number.
-template <typename Source>
-int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
-                    const char* const* names, const kr_params* p, int tabular, int* has_previous, char** text, uint64_t* len,
-                    kr_placement** placements, uint64_t* nplacements, const std::function<void(const char*)>& lap, uint32_t r_begin = 0)
-{ // reads [r_begin, r_begin + nreads) of the batch (a range of it: kr_place_stream works through a batch in ranges)
-  const int nt = std::max(1, std::min(std::min(kr::parallel_width(), 32), (int)(nreads / 4096)));
-  auto en = [&](uint32_t q) { return q - 1; };
-  auto mid = [&](uint32_t q) { return std::isnan(pt->t.nodes[q].blen) ? 0.0 : pt->t.nodes[q].blen / 2.0; };
   // Round 6: the text goes into a raw, growing byte buffer per thread -- room is checked once per number or name, bytes are
   // stored through a pointer -- instead of a std::string appended to character by character (25 appends per placement, each with
   // its capacity test: 13-27 ms per 200,000 reads of jplace on 16 threads, the longest phase of a kr_place_stream call on the
@@ -431,40 +420,95 @@ int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
     size_t size() const { return n; }
     const char* data() const { return b; }
   };
-  auto num = [](OutBuf& o, double v) { // "%.5f" (the reference's stream settings: std::fixed, 5 decimals)
+  // two decimal digits at a time from a table (a division by 10 per digit was a third of a jplace row's time)
+static const char kD2[] = "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+                            "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+inline uint32_t place_digits5(uint32_t nn, char* q)
+{ // nn = round(|v| * 1e5) < 1e8: integer part, '.', five decimals
+    const uint32_t ip = nn / 100000u, fp = nn - ip * 100000u;
+    uint32_t o_ = 0;
+    if (ip >= 100u) {
+      q[o_++] = (char)('0' + ip / 100u);
+      memcpy(q + o_, kD2 + 2u * (ip % 100u), 2), o_ += 2;
+    } else if (ip >= 10u) {
+      memcpy(q + o_, kD2 + 2u * ip, 2), o_ += 2;
+    } else {
+      q[o_++] = (char)('0' + ip);
+    }
+    q[o_++] = '.';
+    const uint32_t a_ = fp / 1000u, b_ = fp - a_ * 1000u; // fp = a_ (2 digits) | b_ (3 digits)
+    memcpy(q + o_, kD2 + 2u * a_, 2);
+    q[o_ + 2] = (char)('0' + b_ / 100u);
+    memcpy(q + o_ + 3, kD2 + 2u * (b_ % 100u), 2);
+    return o_ + 5u;
+}
+inline void place_num(OutBuf& o, double v)
+{ // "%.5f" (the reference's stream settings: std::fixed, 5 decimals)
     o.need(80);
     if (std::isnan(v)) {
       if (std::signbit(v)) o.put('-');
       o.lit("nan", 3);
       return;
     }
-    uint32_t nn;
+    uint32_t nn = 0;
     const double av = std::fabs(v);
-    if (kr::fixed5_exact(av, &nn)) { // printf's digits, exactly (kr_common.h)
+    bool ok = false;
+    if (av < 1000.0) {
+      // round(av * 1e5) as printf rounds the exact binary value: away from a tie the scaled value's own fraction decides (its
+      // rounding error is below 2^-27); within 1e-6 of a tie the exact routine does (kr_common.h: fma, parity)
+      const double sc = av * 100000.0;
+      const uint32_t fi = (uint32_t)sc; // (truncation = floor: sc >= 0)
+      const double fr = sc - (double)fi;
+      if (std::fabs(fr - 0.5) > 1e-6)
+        nn = fi + (fr > 0.5 ? 1u : 0u), ok = true;
+      else
+        ok = kr::fixed5_exact(av, &nn);
+      ok = ok && nn < 100000000u;
+    }
+    if (ok) {
       if (std::signbit(v)) o.put('-');
-      o.n += kr::fixed5_digits(nn, o.b + o.n);
+      o.n += place_digits5(nn, o.b + o.n);
     } else {
       o.n += kr::fmt_fixed5(v, o.b + o.n);
     }
-  };
+}
+
+// Last phase of report_placement (src/query.cpp:283-331) for a whole batch: chi-square filter, LWR, selection, text.
+// `cand(i)` gives candidate i; a read's candidates [c0, c1) are in ascending node number.
+// `src`: reported(r), single(r), fetch(r, buf) -> fills buf with the read's candidates in ascending node number.
+template <typename Source>
+int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
+                    const char* const* names, const kr_params* p, int tabular, int* has_previous, char** text, uint64_t* len,
+                    kr_placement** placements, uint64_t* nplacements, const std::function<void(const char*)>& lap, uint32_t r_begin = 0)
+{ // reads [r_begin, r_begin + nreads) of the batch (a range of it: kr_place_stream works through a batch in ranges)
+  const int nt = std::max(1, std::min(std::min(kr::parallel_width(), 32), (int)(nreads / 4096)));
+  auto en = [&](uint32_t q) { return q - 1; };
+  auto mid = [&](uint32_t q) { return std::isnan(pt->t.nodes[q].blen) ? 0.0 : pt->t.nodes[q].blen / 2.0; };
   auto unum = [](OutBuf& o, uint32_t v) { // decimal
     o.need(12);
     char t_[12];
-    int k_ = 0;
-    do t_[k_++] = (char)('0' + v % 10u), v /= 10u;
-    while (v);
-    while (k_) o.put(t_[--k_]);
+    int k_ = 12;
+    while (v >= 100u) {
+      const uint32_t r_ = v % 100u;
+      v /= 100u;
+      k_ -= 2, memcpy(t_ + k_, kD2 + 2u * r_, 2);
+    }
+    if (v >= 10u)
+      k_ -= 2, memcpy(t_ + k_, kD2 + 2u * v, 2);
+    else
+      t_[--k_] = (char)('0' + v);
+    o.lit(t_ + k_, (size_t)(12 - k_));
   };
   const bool want_pl = placements && nplacements;
   auto jfields = [&](OutBuf& o, uint32_t q, const CandLite& a) {
     o.need(16);
     o.put('[');
     unum(o, en(q));
-    o.need(4), o.lit(", ", 2), num(o, a.jc() - mid(q));
-    o.need(4), o.lit(", ", 2), num(o, mid(q));
-    o.need(4), o.lit(", ", 2), num(o, -a.v);
-    o.need(4), o.lit(", ", 2), num(o, a.lwr);
-    o.need(4), o.lit(", ", 2), num(o, a.d);
+    o.need(4), o.lit(", ", 2), place_num(o, a.jc() - mid(q));
+    o.need(4), o.lit(", ", 2), place_num(o, mid(q));
+    o.need(4), o.lit(", ", 2), place_num(o, -a.v);
+    o.need(4), o.lit(", ", 2), place_num(o, a.lwr);
+    o.need(4), o.lit(", ", 2), place_num(o, a.d);
     o.need(4), o.put(']');
   };
   auto tfields = [&](OutBuf& o, uint32_t q, const CandLite& a) {
@@ -476,8 +520,8 @@ int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
       o.lit(nm.data(), nm.size());
     o.put('\t');
     unum(o, en(q));
-    o.need(4), o.put('\t'), num(o, a.lwr);
-    o.need(4), o.put('\t'), num(o, a.d);
+    o.need(4), o.put('\t'), place_num(o, a.lwr);
+    o.need(4), o.put('\t'), place_num(o, a.d);
   };
   const bool jp = tabular == 0, tb = tabular == 1; // 2: --summarize, no text (the caller sums the placements)
   std::vector<OutBuf> part((size_t)nt);
@@ -610,6 +654,15 @@ int emit_placements(const kr_place_tree* pt, uint32_t nreads, const Source& src,
 extern "C" {
 
 void kr_place_tree_free(kr_place_tree* pt) { delete pt; }
+// tests: one number as the placement rows print it (place_num); returns the length
+int kr_debug_place_fixed5(double v, char* out)
+{
+  OutBuf o;
+  place_num(o, v);
+  memcpy(out, o.b, o.n);
+  out[o.n] = 0;
+  return (int)o.n;
+}
 const uint8_t* kr_place_tree_kinds(const kr_place_tree* pt) { return pt ? pt->kinds.data() : nullptr; }
 
 int kr_place_frame(const kr_place_tree* pt, int which, int tabular, const char* invocation, uint64_t total_qseq, char** text,

@@ -502,6 +502,42 @@ def test_device_formatter_rounding_is_printfs(capi):
     assert lib.kr_batch_collect_text(None, C.byref(txt), C.byref(ln)) == capi.KR_ERR_ARG
 
 
+def test_place_rows_print_numbers_as_printf_does(capi):
+    """The numbers of a `krepp place` row (pendant and distal lengths, -v_llh, LWR, d: std::fixed with 5 decimals, src/query.hpp:202-206)
+    as the host's last phase prints them since round 6 (place_num, kr_place.cpp: the scaled value's own fraction away from a tie, the
+    exact routine next to one, printf beyond 1000): equal to printf's "%.5f" on random values of both signs, on every j / 2^q tie and
+    its neighbours, around the range's ends, NaN."""
+    lib = capi.load()
+    lib.kr_debug_place_fixed5.restype = C.c_int
+    lib.kr_debug_place_fixed5.argtypes = [C.c_double, C.c_char_p]
+    buf = C.create_string_buffer(96)
+
+    def chk(v):
+        n = lib.kr_debug_place_fixed5(float(v), buf)
+        got = buf.value.decode()
+        want = "%.5f" % v if v == v else ("-nan" if np.signbit(v) else "nan")
+        assert n == len(got) and got == want, (v, got, want)
+
+    rng = np.random.default_rng(11)
+    for v in rng.random(20000) * 0.5:
+        chk(v), chk(-v)
+    for v in rng.random(20000) * 1000.0:
+        chk(v), chk(-v)
+    for v in np.exp(rng.normal(0, 6, 5000)):
+        chk(v), chk(-v)
+    for q in range(1, 22):
+        for j in range(0, 1 << min(q, 9)):
+            v = j / float(1 << q)
+            for w in (v, float(np.nextafter(v, 1.0)), float(np.nextafter(v, -1.0)), v + 417.0):
+                chk(w), chk(-w)
+    for i in range(0, 60_000, 11):
+        v = (i + 0.5) / 1e5
+        chk(v), chk(float(np.nextafter(v, 1.0))), chk(float(np.nextafter(v, 0.0))), chk(-v)
+    for v in (0.0, -0.0, 1e-10, -1e-10, 999.99999, 999.999994, 999.999995, 999.9999999, 1000.0, 1000.000004, 12345.678915, -98765.4321, 1e15, -1e15,
+              float("nan"), -float("nan"), float("inf"), -float("inf")):
+        chk(v)
+
+
 def test_cli_usage_errors(capi):
     exe = os.path.join(ROOT, "krepp_amd", "lib", "krepp")
     r = subprocess.run([exe, "seek"], capture_output=True, text=True)
