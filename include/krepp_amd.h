@@ -455,6 +455,8 @@ KR_API int kr_place_stream(const kr_host_index*, const kr_index*, const kr_place
  * (256 / 1024), which its second launch does with the arrays in global scratch (counted in list chunks of 8: an upper
  * bound, 0 when there was none).  Any pointer may be NULL. */
 KR_API void kr_place_counters(uint64_t* device_batches, uint64_t* host_batches, uint64_t* heavy_reads);
+/* Ranges of reads whose `place` rows were written on the device / that the host formatted although device text was asked for. */
+KR_API void kr_place_text_counters(uint64_t* device_ranges, uint64_t* fallback_ranges);
 /* `tabular`: 0 jplace, 1 --tabular, 2 --summarize (no per-read text; feed the placements to
  * kr_place_summary_add).  place --summarize (src/krepp.cpp:466-471,493-497): `wcount` has
  * kr_place_tree_nnodes + 1 doubles, zeroed by the caller before the first batch and indexed by edge + 1. */

@@ -91,7 +91,7 @@ EXPORTS = [
     "kr_debug_front_end", "kr_debug_stream_move", "kr_debug_stream_addrs", "kr_debug_item_placement", "kr_debug_brent", "kr_debug_colour_classes", "kr_llh_batch", "kr_llh_eval_indexed", "kr_batch_timing",
     "kr_place_tree_create", "kr_place_tree_create_lineage", "kr_place_tree_nnodes", "kr_place_summary_add",
     "kr_place_summary_text", "kr_place_tree_free", "kr_place_tree_kinds", "kr_place_batch", "kr_place_stream", "kr_place_frame", "kr_place_counters",
-    "kr_debug_last_d2h_bytes", "kr_debug_place_fixed5", "kr_fastx_open", "kr_fastx_next", "kr_fastx_detach", "kr_fastx_release", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_fastx_pgz_stats", "kr_format_dist", "kr_debug_fixed5", "kr_free", "kr_host_alloc", "kr_host_free",
+    "kr_debug_last_d2h_bytes", "kr_debug_place_fixed5", "kr_place_text_counters", "kr_fastx_open", "kr_fastx_next", "kr_fastx_detach", "kr_fastx_release", "kr_fastx_close", "kr_fastx_parallel_chunks", "kr_fastx_pgz_stats", "kr_format_dist", "kr_debug_fixed5", "kr_free", "kr_host_alloc", "kr_host_free",
     "kr_build_index", "kr_minimizers_cpu", "kr_minimizers_device", "kr_minimizers_free", "kr_last_error", "kr_version",
 ]
 
@@ -636,6 +636,14 @@ def place_counters():
     """(batches whose `place` back end ran on the device, batches sent whole to the host back end) of this process."""
     a, b = C.c_uint64(0), C.c_uint64(0)
     load().kr_place_counters(C.byref(a), C.byref(b), None)
+    return int(a.value), int(b.value)
+
+
+def place_text_counters():
+    """(ranges of reads whose `place` rows were written on the device, ranges the host formatted although device text was on)"""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    load().kr_place_text_counters.restype = None
+    load().kr_place_text_counters(C.byref(a), C.byref(b))
     return int(a.value), int(b.value)
 
 

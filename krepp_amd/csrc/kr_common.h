@@ -168,6 +168,11 @@ struct PlaceTreeArrays {
   const uint32_t* lo = nullptr;     // [pn + 1] smallest node number in the subtree of q
   const uint32_t* idx_to_pt = nullptr; // [nidx + 1]
   const uint32_t* depth = nullptr;  // [pn + 1] number of ancestors of q
+  // for the rows as text on the device (round 6; all null: no device text)
+  const double* blen = nullptr;       // [pn + 1] branch length above q, NaN = none
+  const uint32_t* card = nullptr;     // [pn + 1] leaves below q
+  const char* labels = nullptr;       // node labels back to back
+  const uint32_t* label_off = nullptr; // [pn + 2]
 };
 struct PlaceDeviceResult { // page-locked host arrays owned by the stream, valid until its next place call / batch
   uint32_t nreads = 0;
@@ -179,6 +184,11 @@ struct PlaceDeviceResult { // page-locked host arrays owned by the stream, valid
   uint64_t kept = 0;                 // kept candidates of this range (the next range's go behind them in the host arrays)
   bool overflow = false;             // the device ran out of candidate slots: take the host path for the batch
   uint32_t heavy_reads = 0;          // reads beyond the LDS arrays of kr_place_kernel, done by its second launch (upper bound)
+  // rows as text written on the device (place_device_text_begin): the range's text in page-locked memory; text == nullptr: the
+  // range has to be formatted from the candidates above (device text off, or a flag came up: `text_flags`)
+  const char* text = nullptr;
+  uint64_t text_len = 0;
+  uint64_t text_flags = 0;
 };
 } // namespace kr
 struct kr_stream;
@@ -206,6 +216,10 @@ void big_free(void* p);
 // counters) runs to its end before the stream is used again.  A PlaceDeviceResult is invalid after the next place_device_finish
 // on its stream (the page-locked arrays it points to may have been renewed).
 void place_device_abort(kr_stream* s);
+// Ask for the rows of the batch's ranges as TEXT written on the device (kr_dev_place.inc): call after place_device_begin and before
+// the first place_device_launch.  names: the batch's read ids; tabular 0 = jplace rows, 1 = tabular rows.  Off again at the next
+// place_device_begin.
+int place_device_text_begin(kr_stream* s, const PlaceTreeArrays& T, const char* const* names, uint32_t nreads, int tabular, bool multi);
 
 } // namespace kr
 

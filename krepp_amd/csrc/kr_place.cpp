@@ -14,6 +14,7 @@
 #include "kr_common.h"
 
 #include <algorithm>
+#include <limits>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -37,6 +38,10 @@ struct kr_place_tree {
   std::vector<uint32_t> parent_arr, lo, depth; // depth: number of ancestors (post-order numbering: parents after children)
   std::vector<uint8_t> elig;
   bool postorder = false; // every subtree is the node range [lo[q], q]: what the device kernel's ancestor listing needs
+  // for the rows as text on the device (round 6): branch lengths, labels back to back
+  std::vector<double> blen_arr;
+  std::string label_blob;
+  std::vector<uint32_t> label_off; // [pn + 2]
 };
 
 namespace {
@@ -119,6 +124,7 @@ char* dup_text(const std::string& s, uint64_t* len)
 
 // kr_place_stream batches of this process by back end (kr_place_counters): on the device, or sent whole to the host path
 static std::atomic<uint64_t> g_place_device_batches{0}, g_place_host_batches{0}, g_place_heavy_reads{0};
+std::atomic<uint64_t> g_place_text_device{0}, g_place_text_fallback{0};
 
 extern "C" {
 
@@ -365,6 +371,13 @@ void finish_tree(kr_place_tree& ptr, const kr_index_view& v, bool mapped, bool d
     }
     for (uint32_t se = 1; se <= pn; ++se)
       if (se - pt->lo[se] + 1 != size[se]) pt->postorder = false; // the subtree is not a contiguous range of numbers
+  }
+  pt->blen_arr.assign(pn + 1, std::numeric_limits<double>::quiet_NaN());
+  pt->label_off.assign(pn + 2, 0);
+  pt->label_blob.clear();
+  for (uint32_t se = 0; se <= pn; ++se) {
+    if (se < pt->t.nodes.size()) pt->blen_arr[se] = pt->t.nodes[se].blen, pt->label_blob += pt->t.nodes[se].label;
+    pt->label_off[se + 1] = (uint32_t)pt->label_blob.size();
   }
 }
 
@@ -957,13 +970,19 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
   // Two ranges from 131,072 reads (400,000 reads, tabular, one call at a time: 8.0 M reads/s whole, 12.8 M in two ranges, 10.0 M in
   // four, 9.2 M in eight -- every range has its own launches, waits and copies; a 65,536-read batch of the CLI loses in any split:
   // profiles/round5_place_ranges.txt).  KR_PLACE_RANGES=1: the whole batch at once, as before.
-  uint32_t nranges = nreads >= 131072u ? 2u : 1u;
+  // Round 6: jplace and tabular rows are written on the DEVICE, where the placements are (kr_dev_place.inc), when the caller wants
+  // text and no placement records (the CLI's text modes): the candidates stay in HBM, the range's text comes back as bytes, and
+  // with no last phase on the host there is nothing for a second range to hide.  KR_PLACE_HOST_TEXT=1: the host's last phase.
+  const bool dev_text = (tabular == 0 || tabular == 1) && !(placements && nplacements) && names && pt->card.size() == (size_t)T.pn + 1 && !getenv("KR_PLACE_HOST_TEXT");
+  if (dev_text) T.blen = pt->blen_arr.data(), T.card = pt->card.data(), T.labels = pt->label_blob.data(), T.label_off = pt->label_off.data();
+  uint32_t nranges = (nreads >= 131072u && !dev_text) ? 2u : 1u;
   if (const char* e = getenv("KR_PLACE_RANGES")) nranges = (uint32_t)std::max(1, std::min(16, atoi(e)));
   nranges = std::min<uint32_t>(nranges, std::max<uint32_t>(1u, nreads));
   int rc = kr::place_device_begin(s, pt, T, read_len.data());
   if (rc) return rc;
   if (kr::place_stream_nreads(s) != nreads) return kr::fail(KR_ERR_ARG, "kr_place_stream: nreads does not match the submitted batch");
   auto r_of = [&](uint32_t k) { return (uint32_t)((uint64_t)nreads * k / nranges); };
+  if (dev_text && (rc = kr::place_device_text_begin(s, T, names, nreads, tabular, p->multi != 0))) return rc;
   lap("front end waited for, workspaces");
   if ((rc = kr::place_device_launch(s, T, 0, r_of(1), p->tau, p->no_filter != 0, p->chisq))) return rc;
   struct Piece { char* text = nullptr; uint64_t len = 0; kr_placement* pl = nullptr; uint64_t npl = 0; };
@@ -988,6 +1007,31 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
     kept_base += res.kept;
     if (k + 1 < nranges) // the next range's kernels run beside this range's last phase
       if ((rc = kr::place_device_launch(s, T, r1, r_of(k + 2) - r1, p->tau, p->no_filter != 0, p->chisq))) break;
+    if (dev_text) (res.text ? g_place_text_device : g_place_text_fallback).fetch_add(1, std::memory_order_relaxed);
+    if (dev_text && !res.text && timing) fprintf(stderr, "[place/device] the device's text was not taken: flags %llu (1 a number out of range, 2 more text than the buffer holds, 4 more than 64 candidates kept in a read, 8 a rounding tie too close)\n", (unsigned long long)res.text_flags);
+    if (res.text) { // the range's rows, written on the device
+      const char* tp = res.text;
+      uint64_t tl = res.text_len;
+      if (tabular == 0 && tl >= 2) { // jplace: every reported read begins with ",\n"; the first one of a file loses it
+        if (!prev) tp += 2, tl -= 2;
+        prev = 1;
+      }
+      Piece& pcd = pieces[k];
+      pcd.text = (char*)kr::big_alloc(tl + 1);
+      if (!pcd.text) {
+        rc = kr::fail(KR_ERR_NOMEM, "kr_place_stream: out of memory");
+        break;
+      }
+      const int sl = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::min(kr::parallel_width(), 16), tl >> 20));
+      kr::parallel_for(sl, [&](int q) {
+        const uint64_t l0 = tl * (uint64_t)q / sl, l1 = tl * (uint64_t)(q + 1) / sl;
+        if (l1 > l0) memcpy(pcd.text + l0, tp + l0, l1 - l0);
+      });
+      pcd.text[tl] = 0;
+      pcd.len = tl;
+      lap("D: the device's text taken over");
+      continue;
+    }
     // each read's candidates in ascending node number (the order the host path forms them in), straight from the
     // arrays the device wrote
     struct DeviceSource {
@@ -1051,6 +1095,12 @@ int kr_place_stream(const kr_host_index* hx, const kr_index* dix, const kr_place
   }
   *has_previous = prev;
   return KR_OK;
+}
+
+void kr_place_text_counters(uint64_t* device_ranges, uint64_t* fallback_ranges)
+{ // ranges of reads whose rows were written on the device / that were formatted by the host although device text was asked for
+  if (device_ranges) *device_ranges = g_place_text_device.load(std::memory_order_relaxed);
+  if (fallback_ranges) *fallback_ranges = g_place_text_fallback.load(std::memory_order_relaxed);
 }
 
 void kr_place_counters(uint64_t* device_batches, uint64_t* host_batches, uint64_t* heavy_reads)

@@ -271,6 +271,22 @@ def test_place_on_the_1000_genome_tree_never_leaves_the_device(capi, synth, syn)
         assert len(pl_d) > n // 2
         assert pl_d.tobytes() == pl_h.tobytes() and text_d == text_h
         print(f"heavy reads (upper bound): {heavy} of {n}")
+        # round 6: the rows written on the device (the caller wants text, no placement records): the same bytes, also from the reads
+        # that keep hundreds of candidates here (the toy trees of tests/test_place.py keep at most a few dozen); jplace and tabular
+        t0 = capi.place_text_counters()
+        placer.prev = C.c_int(0)
+        text_dt, _ = placer.place(bases, offs, names, host=False, c_names=c_names, want_placements=False)
+        t1 = capi.place_text_counters()
+        assert (t1[0] - t0[0], t1[1] - t0[1]) == (1, 0), "the rows were formatted by the host"
+        assert text_dt == text_h
+        pj = capi.Placer(hx, None, 0, tabular=False, max_reads=n, max_bases=len(bases))
+        try:
+            want_j, _ = pj.place(bases, offs, names, host=True, c_names=c_names)
+            pj.prev = C.c_int(0)
+            got_j, _ = pj.place(bases, offs, names, host=False, c_names=c_names, want_placements=False)
+            assert got_j == want_j and capi.place_text_counters()[0] == t1[0] + 1
+        finally:
+            pj.close()
     finally:
         placer.close()
         hx.close()

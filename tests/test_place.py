@@ -285,6 +285,60 @@ def test_device_back_end_equals_host_back_end(capi, po, toy_index_dir, toy_reads
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tree", ["backbone", "user", "lineages"])
+def test_rows_written_on_the_device_equal_the_host_s(capi, po, toy_index_dir, toy_reads, toy_genomes, synth, tree, monkeypatch):
+    """Round 6: when the caller wants text and no placement records (the CLI's jplace and tabular modes), kr_place_stream has the rows
+    written on the DEVICE (kr_place_text_* kernels: chi-square filter, LWR, Jukes-Cantor, "%.5f" digits, jplace framing) and copies
+    bytes back.  Byte for byte the text of the host's last phase (kr_place_batch, which the oracle comparisons above pin): every
+    tree, option set and text mode; two calls in a row (the ",\n" between the reads of a jplace file); several ranges; and with the
+    device text switched off (KR_PLACE_HOST_TEXT) the same again."""
+    names, bases, offs = toy_reads
+    b2, o2, n2 = synth.sample_reads(toy_genomes, 6000, seed=31)
+    hx = capi.HostIndex(toy_index_dir)
+    kw = {}
+    if tree == "user":
+        nwk = open(os.path.join(GOLDEN, "tree_toy.nwk")).read()
+        kw["nwk_text"] = nwk.replace("(G000735195:0.0276038,G000018865:0.0228997)N2640:0.160977", "(G000735195:0.03,NEWLEAF:0.02)N2640:0.160977")
+    elif tree == "lineages":
+        kw["lineage_text"] = open(os.path.join(GOLDEN, "lineages_toy.txt")).read()
+    lib = capi.load()
+
+    def texts(pl, host, want_pl):
+        out = []
+        for rb, ro, rn in ((bases, offs, names), (b2, o2, n2)):  # two calls on one Placer: `prev` carries over
+            t, _ = pl.place(rb, ro, rn, host=host, want_placements=want_pl)
+            out.append(t)
+        return out
+
+    for opts in (dict(), dict(multi=0), dict(tau=1, chisq=3.841), dict(hdist_th=3)):
+        for tabular in (0, 1):
+            mk = lambda: capi.Placer(hx, kw.get("nwk_text"), 0, tabular=tabular, max_reads=len(n2), max_bases=len(b2), lineage_text=kw.get("lineage_text"), **opts)
+            pl = mk()
+            want = texts(pl, True, True)  # the host back end
+            pl.close()
+            assert sum(len(t) for t in want) > 10000
+            for ranges in (None, "3"):
+                if ranges:
+                    monkeypatch.setenv("KR_PLACE_RANGES", ranges)
+                pl = mk()
+                d0 = capi.place_text_counters()
+                got = texts(pl, False, False)  # device back end, text from the device
+                d1 = capi.place_text_counters()
+                pl.close()
+                assert got == want, (tree, opts, tabular, ranges)
+                assert d1[0] - d0[0] == (2 if not ranges else 6) and d1[1] == d0[1], "the rows were not written on the device"
+                if ranges:
+                    monkeypatch.delenv("KR_PLACE_RANGES")
+            monkeypatch.setenv("KR_PLACE_HOST_TEXT", "1")
+            pl = mk()
+            d0 = capi.place_text_counters()
+            assert texts(pl, False, False) == want
+            assert capi.place_text_counters() == d0
+            pl.close()
+            monkeypatch.delenv("KR_PLACE_HOST_TEXT")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ranges", ["1", "2", "3", "16"])
 def test_ranges_of_a_batch_give_the_batch_s_output(capi, po, toy_index_dir, toy_reads, toy_genomes, synth, monkeypatch, ranges):
     """kr_place_stream works through a batch in ranges of reads (the host's last phase of one range beside the place kernels of the
