@@ -420,6 +420,10 @@ struct CandLite { // what the last phase needs of a candidate
         if (cap < k + 65536) {
           kr::big_free(b);
           b = (char*)malloc(k + 65536), cap = b ? k + 65536 : 0;
+          if (!b) { // (not even that: nothing sensible is left to do -- the std::string this replaces would have thrown here)
+            fprintf(stderr, "[ERROR] krepp place: out of memory\n");
+            abort();
+          }
         }
         return;
       }
