@@ -2,9 +2,10 @@
 # round 6, session 40: per-kernel times of both workloads at HEAD (rocprofv3 --kernel-trace --stats only)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/s40
 export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8 KR_ITEM_PLACEMENT_TRIALS=0
+D=$(mktemp -d /tmp/krprof.XXXXXX)
 for wl in syn1000 syn10000; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$wl -- python3 bench.py --workload $wl --steps 4 --warmup 1 --no-cpu-baseline --no-host-inclusive --read-procs 1 --distinct-batches 1 --skip-host-path-check > gpurun_out/s40/bench_$wl.log 2>&1
-  f=$(find /tmp/prof_$wl -name "*kernel_stats.csv" | head -n 1)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof_$wl -- python3 bench.py --workload $wl --steps 4 --warmup 1 --no-cpu-baseline --no-host-inclusive --read-procs 1 --distinct-batches 1 --skip-host-path-check > gpurun_out/s40/bench_$wl.log 2>&1
+  f=$(grep -l kr_scan_pipe $(find $D/prof_$wl -name "*kernel_stats.csv") | head -n 1) # (the bench's own process, not its helpers')
   python3 - "$f" $wl <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
