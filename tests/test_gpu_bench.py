@@ -112,8 +112,9 @@ def test_bench_eight_ranks_at_the_full_table_size():
     FULL 10 GB table -- eight replicas of the 19 GB index and eight 1 M-read streams resident together --, the index built and
     inflated once and replicated seven times, every rank generating its shard on `usable_cpus() // 8` worker processes; the set-up
     stays under two minutes, the rows of rank 0's timed launch equal the oracle's and, all of them, an independent stream's.
-    (KR_ACC_SCRATCH_GB=2: a stream sizes its accumulate scratch for the 10,000-leaf tree at 16 GB, and eight of those beside eight
-    replicas do not fit ONE GPU's 288 GB -- a rank that owns its GPU does not need the cap.)"""
+    (KR_ACC_SCRATCH_GB=2: a stream budgets its accumulate scratch by the device memory that is free when it is made -- a sixth of it,
+    8..48 GB, 26 GB of which the 10,000-leaf tree uses at full residency -- and eight ranks that each see the whole GPU as theirs would
+    not fit beside eight replicas in ONE GPU's 288 GB; a rank that owns its GPU does not need the cap.)"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env["KR_ACC_SCRATCH_GB"] = "2"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--ranks-share-device", "--workload", "syn10000",
