@@ -324,6 +324,45 @@ def test_single_segment_many_leaves_spill_paths(capi, po, synth, tmp_path, monke
     assert_rows_close(res.rows(), rows_of_oracle(ref))
 
 
+@pytest.mark.parametrize("n", [160, 330])
+def test_report_modes_on_reads_of_many_records(capi, po, synth, tmp_path, n):
+    """The selection (src/query.cpp:96-139,158-196) of reads with MANY records, in every report mode.  On the benchmark indexes one read
+    in eight has more than 64 records and those hold two thirds of all records; the select kernel does them by the whole wave
+    (select_big_read: up to 256 records in registers, more in two passes through memory), and the golden report-mode tests run on the
+    25-reference index, where no read has more than 50.  160 / 330 close relatives: a read has ~n records (one strand of nearly every
+    leaf) up to 2 n.  Default, --no-multi, --dist-max, both, --filter; plain batches and rows-only batches with DIST as an index."""
+    names = [f"s{i}" for i in range(n)]
+    nwk = "(" + ",".join(f"{x}:0.003" for x in names) + ");"
+    g = synth.evolve_genomes(nwk, 4000 if n == 160 else 2500, seed=23)
+    tsv = synth.write_genomes(g, str(tmp_path / "g"))
+    (tmp_path / "t.nwk").write_text(nwk)
+    idx = str(tmp_path / "ix")
+    capi.build_index(tsv, idx, nwk=str(tmp_path / "t.nwk"), k=29, w=31, h=13, m=2, r=0, frac=True, num_threads=4)
+    hx = capi.HostIndex(idx)
+    dx = hx.upload(0)
+    ox = po.Index(idx)
+    nreads = 260
+    bases, offs, rn = synth.sample_reads(g, nreads, seed=4)
+    seen_mid = seen_big = False
+    for pkw in (dict(), dict(multi=0), dict(dist_max=0.005), dict(multi=0, dist_max=0.005), dict(no_filter=0)):
+        want = rows_of_oracle(ox.dist(bases, offs, rn, po.params(collect=0, **pkw)))
+        for flags in (0, capi.KR_ROWS_ONLY | capi.KR_ROWS_INDEXED):
+            if flags and "no_filter" in pkw:
+                continue  # (rows as indices are for batches without --filter)
+            st = dx.stream(params=capi.default_params(**pkw), max_reads=nreads, max_bases=len(bases), max_records=nreads * 2 * n)
+            st.submit(bases, offs, flags)
+            res = st.collect()
+            got = res.rows() if not flags else sorted(zip(res.rec_read.tolist(), (res.rec_key >> 1).tolist(), res.rec_d.tolist()))  # (a rows-only batch holds rows only)
+            assert_rows_close(got, want)
+            if not flags:
+                cnt = res.read_cnt
+                seen_mid |= bool(((cnt > 64) & (cnt <= 256)).any())
+                seen_big |= bool((cnt > 256).any())
+            st.close()
+    assert len(want) > 0
+    assert seen_mid if n == 160 else seen_big  # the point of the test
+
+
 def test_many_leaves_bitmap_spans_several_tiles(capi, po, synth, tmp_path):
     """2,300 references: 4,600 (leaf, strand) keys = 72 bitmap blocks, more than one 64-lane tile of the ordinal
     prefix, and level-2 / merge lists longer than a wave (the 10k-genome configuration in the small)."""
