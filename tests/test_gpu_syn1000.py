@@ -11,7 +11,8 @@ bit-exact, DIST within the north star's 1e-6 relative — then a full 1,000,000-
 properties (reverse complement, permutation, split); on the default layout (and on the filter slots) the same three properties
 once more at 8,000,000 reads per launch -- the size of bench.py's timed launches (4,000,000 on the filter slots) (item lists of hundreds of millions of
 entries, every cursor range in use; the byte-table front end, finalize_events_fast, kr_select_lane_kernel and the row compaction
-all on their default paths) -- compared through an order-independent 128-bit checksum of the rows.
+all on their default paths) -- compared through an order-independent checksum of the rows: of a rows-only batch (and its
+KR_ROWS_INDEXED form) copied back, then of plain batches where their rows lie in HBM.
 """
 import os
 
@@ -37,6 +38,46 @@ def rows_checksum(read, se, dbits):
         h *= np.uint64(0x94D049BB133111EB)
         h ^= h >> np.uint64(31)
         return int(h.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(h)), int(len(h))
+
+
+def rows_checksum_device(torch, dev, st, nreads, read_map=None, read_add=0, chunk=1 << 20):
+    """(sum, count) of rows_checksum over the rows the stream's last launch left in its DEVICE arrays (kr_batch_collect_device), computed
+    there: 265 M rows of an 8 M-read launch need not cross PCIe and numpy to be compared.  read_map: int64 tensor on the device."""
+    from bench import dev_array
+
+    rv = st.collect_device()
+    off_all = dev_array(torch, dev, rv.read_off, nreads, torch.int32)
+    cnt_all = dev_array(torch, dev, rv.read_cnt, nreads, torch.int32)
+    key_all = dev_array(torch, dev, rv.rec_key, rv.nrecs, torch.int32)
+    sel_all = dev_array(torch, dev, rv.rec_sel, rv.nrecs, torch.uint8)
+    d_all = dev_array(torch, dev, rv.rec_d, rv.nrecs, torch.int64)  # the f64's bits
+    M = (1 << 64) - 1
+    lsr = lambda x, k: (x >> k) & ((1 << (64 - k)) - 1)
+    i64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v
+    total = rows = 0
+    for r0 in range(0, nreads, chunk):
+        r1 = min(nreads, r0 + chunk)
+        cnt = cnt_all[r0:r1].to(torch.int64)
+        tot = int(cnt.sum().item())
+        if not tot:
+            continue
+        first = torch.cumsum(cnt, 0) - cnt
+        rd = torch.repeat_interleave(torch.arange(r1 - r0, device=dev), cnt)
+        idx = off_all[r0:r1].to(torch.int64)[rd] + (torch.arange(tot, device=dev) - first[rd])
+        key = key_all[idx].to(torch.int64) & 0xFFFFFFFF
+        keep = (sel_all[idx] != 0) & (key != 0)
+        rd, key, d = rd[keep] + r0, key[keep] >> 1, d_all[idx][keep]
+        if read_map is not None:
+            rd = read_map[rd]
+        h = (rd + read_add) * i64(0x9E3779B97F4A7C15) + key  # (int64 arithmetic wraps like rows_checksum's uint64)
+        h = h ^ lsr(h, 29)
+        h = h * i64(0xBF58476D1CE4E5B9) + d
+        h = h ^ lsr(h, 32)
+        h = h * i64(0x94D049BB133111EB)
+        h = h ^ lsr(h, 31)
+        total = (total + int(h.sum().item())) & M
+        rows += int(keep.sum().item())
+    return total, rows
 
 
 @pytest.fixture(scope="module")
@@ -170,13 +211,23 @@ def test_syn1000_10gb_index_vs_oracle_and_full_batch_properties(capi, po, synth,
                 assert sti.last_d2h_bytes() < 0.8 * plain_bytes
                 del ri
                 sti.close()
-            assert run_sum(synth.COMP[bases.reshape(n, 150)[:, ::-1]].reshape(-1), offs) == base_sum, "full launch: reverse complement changes the rows"
+            # the properties on PLAIN batches (what bench.py's timed leg submits), their rows summed where they lie, in HBM: the rows-only
+            # batch above crossed PCIe and numpy (3.2 GB, half a minute a launch); these do not
+            def run_dev(b_, o_, read_map=None, read_add=0):
+                stl.submit(b_, o_)
+                stl.wait()
+                return rows_checksum_device(torch, dev, stl, len(o_) - 1, read_map, read_add)
+
+            base_dev = (base_sum[0], base_sum[2])
+            assert run_dev(bases, offs) == base_dev, "full launch: a plain batch's rows differ from the rows-only batch's"
+            assert run_dev(synth.COMP[bases.reshape(n, 150)[:, ::-1]].reshape(-1), offs) == base_dev, "full launch: reverse complement changes the rows"
             perm = np.random.default_rng(2).permutation(n)
-            assert run_sum(bases.reshape(n, 150)[perm].reshape(-1), offs, read_map=perm) == base_sum, "full launch: permutation changes the rows"
+            assert run_dev(bases.reshape(n, 150)[perm].reshape(-1), offs, read_map=torch.from_numpy(perm.astype(np.int64)).to(dev)) == base_dev, \
+                "full launch: permutation changes the rows"
             half = n // 2
-            a = run_sum(bases[: half * 150], offs[: half + 1])
-            b = run_sum(bases[half * 150:], offs[half:] - offs[half], read_add=half)
-            assert ((a[0] + b[0]) % (1 << 64), a[1] ^ b[1], a[2] + b[2]) == base_sum, "full launch: splitting the batch changes the rows"
+            a = run_dev(bases[: half * 150], offs[: half + 1])
+            b = run_dev(bases[half * 150:], offs[half:] - offs[half], read_add=half)
+            assert ((a[0] + b[0]) % (1 << 64), a[1] + b[1]) == base_dev, "full launch: splitting the batch changes the rows"
             stl.close()
     finally:
         dx.close()
